@@ -1,0 +1,203 @@
+"""Generate tests/golden/*.npz from the reference's HF-Transformers Whisper path.
+
+Run ONLY in the build container (needs `transformers`; the GPU box never runs this):
+    python oracle/make_golden.py
+Inputs are the seeded synthetic weights/clips of taiwan_tongues_asr_ce_amd.synth; outputs are what the
+HF classes the reference trains/evaluates with (train_asr.py:33-43,518-545) compute on them:
+WhisperFeatureExtractor, WhisperForConditionalGeneration (encoder, cached decoder), and the
+Suppress*/WhisperTimeStamp logits processors.  Fixtures are data only (no reference source text).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from transformers import WhisperConfig, WhisperFeatureExtractor, WhisperForConditionalGeneration  # noqa: E402
+from transformers.generation.logits_process import (  # noqa: E402
+    SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor, WhisperTimeStampLogitsProcessor)
+
+from taiwan_tongues_asr_ce_amd import synth  # noqa: E402
+from taiwan_tongues_asr_ce_amd.config import PRESETS, SpecialTokens, NON_SPEECH_TOKENS_MULTI  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def hf_model(dims, seed=0, dtype=torch.float32):
+    st = SpecialTokens.for_vocab(dims.vocab)
+    cfg = WhisperConfig(
+        vocab_size=dims.vocab, num_mel_bins=dims.n_mels, d_model=dims.d_model,
+        encoder_layers=dims.enc_layers, encoder_attention_heads=dims.n_heads, encoder_ffn_dim=dims.ffn_dim,
+        decoder_layers=dims.dec_layers, decoder_attention_heads=dims.n_heads, decoder_ffn_dim=dims.ffn_dim,
+        max_source_positions=dims.n_audio_ctx, max_target_positions=dims.n_text_ctx,
+        pad_token_id=st.eot, bos_token_id=st.eot, eos_token_id=st.eot, decoder_start_token_id=st.sot,
+        activation_function="gelu", attn_implementation="eager")
+    model = WhisperForConditionalGeneration(cfg).eval()
+    sd = {k: torch.from_numpy(v) for k, v in synth.iter_weights(dims, seed)}
+    sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("proj_out" in m for m in missing), missing
+    return model.to(dtype), st
+
+
+def hf_processors(st, begin_index, timestamps, suppress, begin_suppress, max_initial=50):
+    procs = [SuppressTokensAtBeginLogitsProcessor(begin_suppress, begin_index=begin_index),
+             SuppressTokensLogitsProcessor(suppress)]
+    if timestamps:
+        gc = types.SimpleNamespace(no_timestamps_token_id=st.no_timestamps, eos_token_id=st.eot,
+                                   bos_token_id=st.eot, max_initial_timestamp_index=max_initial,
+                                   _detect_timestamp_from_logprob=True)
+        procs.append(WhisperTimeStampLogitsProcessor(gc, begin_index=begin_index))
+    return procs
+
+
+def hf_greedy(model, st, enc, prompt, n_steps, timestamps, suppress, begin_suppress):
+    """Greedy loop over HF's cached decoder + HF's processor classes; stops rows at EOT."""
+    B = enc.shape[0]
+    procs = hf_processors(st, len(prompt), timestamps, suppress, begin_suppress)
+    ids = torch.tensor([prompt] * B, dtype=torch.long)
+    out = model(encoder_outputs=(enc,), decoder_input_ids=ids, use_cache=True)
+    past = out.past_key_values
+    prompt_logits = out.logits.float().clone()
+    logits = out.logits[:, -1].float()
+    raw, toks = [], []
+    done = torch.zeros(B, dtype=torch.bool)
+    for _ in range(n_steps):
+        raw.append(logits.clone())
+        s = logits
+        for p in procs:
+            s = p(ids, s)
+        nxt = s.argmax(-1)
+        nxt = torch.where(done, torch.full_like(nxt, st.eot), nxt)
+        toks.append(nxt.clone())
+        done |= nxt == st.eot
+        ids = torch.cat([ids, nxt[:, None]], dim=1)
+        if ids.shape[1] >= model.config.max_target_positions or bool(done.all()):
+            break
+        out = model(encoder_outputs=(enc,), decoder_input_ids=nxt[:, None], past_key_values=past, use_cache=True)
+        past = out.past_key_values
+        logits = out.logits[:, -1].float()
+    return torch.stack(raw).numpy(), torch.stack(toks).numpy(), prompt_logits.numpy(), past
+
+
+def golden_mel():
+    clips = {"noise": synth.noise_clip(0), "tonal": synth.tonal_clip(0), "burst": synth.burst_clip(0),
+             "short": synth.noise_clip(5, 176102)}  # warm_up.wav length after resampling
+    out = {}
+    for M in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=M)
+        out[f"filters_{M}"] = np.asarray(fe.mel_filters, dtype=np.float32)
+        for name, pcm in clips.items():
+            mel = fe(pcm, sampling_rate=16000, return_tensors="np")["input_features"][0]
+            assert mel.shape == (M, 3000)
+            out[f"{name}_{M}_stride7"] = mel[:, ::7].astype(np.float32)
+            out[f"{name}_{M}_head"] = mel[:, :16].astype(np.float32)
+            out[f"{name}_{M}_tail"] = mel[:, -16:].astype(np.float32)
+            out[f"{name}_{M}_sum"] = np.array([mel.astype(np.float64).sum(), np.abs(mel).astype(np.float64).sum()])
+    np.savez_compressed(os.path.join(OUT, "mel.npz"), **out)
+    print("mel.npz", {k: v.shape for k, v in list(out.items())[:4]})
+
+
+def golden_micro():
+    dims = PRESETS["micro"]
+    model, st = hf_model(dims)
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels, chunk_length=1)
+    n = dims.n_frames * 160
+    pcm = np.stack([synth.noise_clip(i, n) for i in range(3)])
+    pcm[2, n // 3:] = 0.0
+    mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
+    eo = model.model.encoder(torch.from_numpy(mel), output_hidden_states=True)
+    enc = eo.last_hidden_state
+    prompt = [st.sot, st.lang_zh, st.transcribe]
+    suppress = [1, 2, 7, st.sot, st.sot_prev, st.no_speech, st.translate, st.transcribe, st.lang_zh]
+    begin_suppress = [5, st.eot]
+    out = dict(pcm=pcm, mel=mel, enc=enc.numpy(), prompt=np.array(prompt), suppress=np.array(suppress),
+               begin_suppress=np.array(begin_suppress))
+    for i, h in enumerate(eo.hidden_states):
+        out[f"enc_hidden_{i}"] = h.numpy()
+    raw, toks, plog, past = hf_greedy(model, st, enc, prompt, 24, True, suppress, begin_suppress)
+    out["ts_logits"], out["ts_tokens"], out["prompt_logits"] = raw, toks, plog
+    cc = past.cross_attention_cache
+    out["cross_k0"] = cc.layers[0].keys.numpy()
+    out["cross_v0"] = cc.layers[0].values.numpy()
+    out["cross_k1"] = cc.layers[1].keys.numpy()
+    raw, toks, _, _ = hf_greedy(model, st, enc, prompt + [st.no_timestamps], 24, False, suppress, begin_suppress)
+    out["nots_logits"], out["nots_tokens"] = raw, toks
+    np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
+    print("micro.npz tokens(ts)", toks.T.tolist()[0][:12], "enc", enc.shape)
+
+
+def golden_tiny():
+    dims = PRESETS["tiny"]
+    model, st = hf_model(dims)
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    pcm = [synth.noise_clip(0), synth.tonal_clip(1)]
+    mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
+    enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state
+    suppress = list(NON_SPEECH_TOKENS_MULTI) + [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]
+    begin_suppress = [220, st.eot]
+    out = dict(enc_stride=enc[:, ::25, ::3].numpy(), enc_mean=enc.mean((1, 2)).numpy(),
+               enc_std=enc.std((1, 2)).numpy(), suppress=np.array(suppress),
+               begin_suppress=np.array(begin_suppress))
+    for tag, prompt, ts in (("ts", [st.sot, st.lang_zh, st.transcribe], True),
+                            ("nots", [st.sot, st.lang_zh, st.transcribe, st.no_timestamps], False)):
+        raw, toks, plog, _ = hf_greedy(model, st, enc, prompt, 20, ts, suppress, begin_suppress)
+        top = torch.from_numpy(raw[0]).topk(32, dim=-1)
+        out[f"{tag}_prompt"] = np.array(prompt)
+        out[f"{tag}_tokens"] = toks
+        out[f"{tag}_top_ids"] = top.indices.numpy()
+        out[f"{tag}_top_vals"] = top.values.numpy()
+        out[f"{tag}_logits_stride"] = raw[:, :, ::97]
+        out[f"{tag}_no_speech"] = torch.softmax(torch.from_numpy(plog[:, 0]), -1)[:, st.no_speech].numpy()
+        print("tiny", tag, toks.T.tolist())
+    np.savez_compressed(os.path.join(OUT, "tiny.npz"), **out)
+
+
+def golden_rules():
+    """Processor known-answer vectors: random rows + hand-built histories -> HF-processed rows."""
+    st = SpecialTokens.for_vocab(512)
+    V = 512
+    g = torch.Generator().manual_seed(7)
+    tb, eot = st.timestamp_begin, st.eot
+    histories = [[], [tb + 3], [tb + 3, 17], [17, 18], [tb + 1, 20, tb + 5], [tb + 1, 20, tb + 5, tb + 5],
+                 [tb, tb], [tb + 2, 9, 10, tb + 40, tb + 40, 33], [tb + 63], [11, tb + 62, tb + 62]]
+    suppress = [1, 2, 7, st.sot, st.no_speech]
+    begin_suppress = [5, eot]
+    rows, outs_ts, outs_nots, hist_pad = [], [], [], []
+    for k, h in enumerate(histories):
+        for variant in range(3):
+            row = torch.randn(V, generator=g) * 3.0
+            if variant == 1:
+                row[tb:] += 4.0  # timestamp mass dominates -> force-timestamp branch
+            if variant == 2:
+                row[:tb] += 6.0
+            prompt = [st.sot, st.lang_zh, st.transcribe]
+            ids = torch.tensor([prompt + h], dtype=torch.long)
+            for ts, store in ((True, outs_ts), (False, outs_nots)):
+                s = row[None].clone()
+                for p in hf_processors(st, len(prompt), ts, suppress, begin_suppress):
+                    s = p(ids, s)
+                store.append(s[0].numpy())
+            rows.append(row.numpy())
+            hist_pad.append(np.array(h + [-1] * (8 - len(h))))
+    np.savez_compressed(os.path.join(OUT, "rules.npz"), rows=np.stack(rows), out_ts=np.stack(outs_ts),
+                        out_nots=np.stack(outs_nots), hist=np.stack(hist_pad), suppress=np.array(suppress),
+                        begin_suppress=np.array(begin_suppress))
+    print("rules.npz", len(rows))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    golden_mel()
+    golden_rules()
+    golden_micro()
+    golden_tiny()

@@ -1,0 +1,378 @@
+"""CPU restatement of the Whisper inference hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+path (taiwan_tongues_asr_ce_amd) never does and fails loudly when its HIP library is missing.
+
+What it restates.  The reference's hot path lives in un-vendored third-party code
+(faster-whisper >= 0.9.0 / CTranslate2, requirements.txt:10; call sites asr_core.py:141,159-167,
+api/file_asr.py:188,457-465, api/stt_streaming/src/asr/faster_whisper_asr.py:107,170).  Neither package is
+installed or installable here, so the arithmetic is restated from the reference's *other* Whisper
+implementation, HF Transformers (train_asr.py:33-43,518-545), citing
+  [HF-FE]  transformers/models/whisper/feature_extraction_whisper.py
+  [HF-M]   transformers/models/whisper/modeling_whisper.py
+  [HF-LP]  transformers/generation/logits_process.py
+  [HF-G]   transformers/models/whisper/generation_whisper.py
+(transformers 5.15.0).  Pinning: tests/golden/*.npz hold outputs of that HF code run in the build
+container on seeded synthetic weights (oracle/make_golden.py is the generating script);
+tests/test_oracle_golden.py checks every function below against them.  The reference has no golden
+vectors of its own for this path (api/tests/test_file_asr.py:40-60 mocks the model), and parity with the
+CTranslate2 engine itself is unpinned (it cannot be run here).
+
+Everything is float32 torch-CPU tensor algebra written from the formulas; no HF model class is used.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+NEG_INF = float("-inf")
+
+
+# --------------------------------------------------------------------------------------------------
+# a5: log-mel front-end
+# --------------------------------------------------------------------------------------------------
+def _hz_to_mel_slaney(f: np.ndarray) -> np.ndarray:
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3.0
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    with np.errstate(divide="ignore"):
+        logpart = min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep
+    return np.where(f >= min_log_hz, logpart, mels)
+
+
+def _mel_to_hz_slaney(m: np.ndarray) -> np.ndarray:
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3.0
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filter_bank(n_mels: int, n_fft: int = 400, sr: int = 16000, fmin: float = 0.0,
+                    fmax: float = 8000.0) -> np.ndarray:
+    """[n_fft//2+1, n_mels] triangular slaney-scale, slaney-normalised filters.
+    Same construction as [HF-FE]:95-103 (mel_filter_bank(norm="slaney", mel_scale="slaney"))."""
+    n_freqs = n_fft // 2 + 1
+    fft_freqs = np.linspace(0.0, sr / 2.0, n_freqs)
+    mel_pts = np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2)
+    hz_pts = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(hz_pts)
+    slopes = hz_pts[None, :] - fft_freqs[:, None]  # [n_freqs, n_mels+2]
+    down = -slopes[:, :-2] / fdiff[:-1]
+    up = slopes[:, 2:] / fdiff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (hz_pts[2:n_mels + 2] - hz_pts[:n_mels])
+    fb *= enorm[None, :]
+    return fb.astype(np.float32)
+
+
+def hann_window(n: int = 400) -> np.ndarray:
+    """Periodic Hann (torch.hann_window default), [HF-FE]:143."""
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)).astype(np.float64)
+
+
+def log_mel(pcm: np.ndarray, n_mels: int, n_samples: int = 480000, n_fft: int = 400, hop: int = 160
+            ) -> np.ndarray:
+    """f32[n] -> f32[n_mels, n_samples//hop].  Follows [HF-FE]:135-168: pad/trim to n_samples, centred
+    STFT with reflect padding, drop the last frame (:154), power, mel matmul (:157),
+    log10(clamp 1e-10) (:159), max(x, clip_max - 8) (:160-162), (x + 4) / 4 (:165).
+    The DFT is done in float64 (ground truth for both the f32 HF path and the f32 HIP kernel)."""
+    x = np.zeros(n_samples, dtype=np.float64)
+    n = min(len(pcm), n_samples)
+    x[:n] = np.asarray(pcm[:n], dtype=np.float64)
+    pad = n_fft // 2
+    xp = np.pad(x, (pad, pad), mode="reflect")
+    n_frames = n_samples // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = xp[idx] * hann_window(n_fft)[None, :]
+    spec = np.fft.rfft(frames, axis=1)
+    power = spec.real ** 2 + spec.imag ** 2  # [frames, 201]
+    mel = power @ mel_filter_bank(n_mels, n_fft).astype(np.float64)  # [frames, n_mels]
+    logm = np.log10(np.maximum(mel, 1e-10))
+    logm = np.maximum(logm, logm.max() - 8.0)
+    logm = (logm + 4.0) / 4.0
+    return np.ascontiguousarray(logm.T).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# weights
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class Dims:
+    n_mels: int
+    n_audio_ctx: int
+    d_model: int
+    n_heads: int
+    ffn_dim: int
+    enc_layers: int
+    dec_layers: int
+    vocab: int
+    n_text_ctx: int = 448
+
+
+def to_torch(sd: Dict[str, np.ndarray], round_bf16: bool = False) -> Dict[str, torch.Tensor]:
+    """numpy state dict -> torch f32.  round_bf16 rounds every matrix the bf16 engine stores in bf16
+    (all >=2-D tensors) so the oracle sees the same weight values as the bf16 kernels."""
+    out = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(np.ascontiguousarray(v)).float()
+        if round_bf16 and t.dim() >= 2:
+            t = t.bfloat16().float()
+        out[k] = t
+    return out
+
+
+def _ln(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def _gelu(x: torch.Tensor) -> torch.Tensor:
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def _lin(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+    y = x @ W[p + ".weight"].t()
+    b = W.get(p + ".bias")
+    return y if b is None else y + b
+
+
+def _split_heads(x: torch.Tensor, H: int) -> torch.Tensor:
+    B, T, d = x.shape
+    return x.view(B, T, H, d // H).permute(0, 2, 1, 3)
+
+
+def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[torch.Tensor] = None
+            ) -> torch.Tensor:
+    """q already scaled ([HF-M]:309: scaling is applied to q_proj output, attention called with 1.0)."""
+    s = q @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s + mask
+    p = torch.softmax(s, dim=-1)
+    o = p @ v  # [B,H,Tq,hd]
+    B, H, Tq, hd = o.shape
+    return o.permute(0, 2, 1, 3).reshape(B, Tq, H * hd)
+
+
+# --------------------------------------------------------------------------------------------------
+# a6 + a7: encoder
+# --------------------------------------------------------------------------------------------------
+def encoder_stem(mel: torch.Tensor, W: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """[B,M,2T] -> [B,T,d]: gelu(conv1 k3 s1 p1), gelu(conv2 k3 s2 p1), transpose, + positions
+    ([HF-M]:618-624)."""
+    x = _gelu(F.conv1d(mel, W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], stride=1, padding=1))
+    x = _gelu(F.conv1d(x, W["model.encoder.conv2.weight"], W["model.encoder.conv2.bias"], stride=2, padding=1))
+    x = x.permute(0, 2, 1)
+    return x + W["model.encoder.embed_positions.weight"][None, : x.shape[1]]
+
+
+def encoder_layer(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str, H: int) -> torch.Tensor:
+    """Pre-LN block, [HF-M]:380-413."""
+    hd = x.shape[-1] // H
+    h = _ln(x, W[p + ".self_attn_layer_norm.weight"], W[p + ".self_attn_layer_norm.bias"])
+    q = _split_heads(_lin(h, W, p + ".self_attn.q_proj") * (hd ** -0.5), H)
+    k = _split_heads(_lin(h, W, p + ".self_attn.k_proj"), H)
+    v = _split_heads(_lin(h, W, p + ".self_attn.v_proj"), H)
+    x = x + _lin(_attend(q, k, v), W, p + ".self_attn.out_proj")
+    h = _ln(x, W[p + ".final_layer_norm.weight"], W[p + ".final_layer_norm.bias"])
+    return x + _lin(_gelu(_lin(h, W, p + ".fc1")), W, p + ".fc2")
+
+
+def encoder_forward(mel: torch.Tensor, W: Dict[str, torch.Tensor], dims: Dims,
+                    return_hidden: bool = False):
+    x = encoder_stem(mel, W)
+    hidden = [x]
+    for i in range(dims.enc_layers):
+        x = encoder_layer(x, W, f"model.encoder.layers.{i}", dims.n_heads)
+        hidden.append(x)
+    x = _ln(x, W["model.encoder.layer_norm.weight"], W["model.encoder.layer_norm.bias"])
+    return (x, hidden) if return_hidden else x
+
+
+# --------------------------------------------------------------------------------------------------
+# a8: cross-attention K/V, a9: decoder step
+# --------------------------------------------------------------------------------------------------
+def cross_kv(enc: torch.Tensor, W: Dict[str, torch.Tensor], dims: Dims
+             ) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """Per decoder layer (K, V) as [B,H,T,hd]; K has no bias ([HF-M]:279,331-335)."""
+    out = []
+    for i in range(dims.dec_layers):
+        p = f"model.decoder.layers.{i}.encoder_attn"
+        out.append((_split_heads(_lin(enc, W, p + ".k_proj"), dims.n_heads),
+                    _split_heads(_lin(enc, W, p + ".v_proj"), dims.n_heads)))
+    return out
+
+
+@dataclass
+class SelfCache:
+    k: List[Optional[torch.Tensor]]
+    v: List[Optional[torch.Tensor]]
+
+    @staticmethod
+    def empty(n_layers: int) -> "SelfCache":
+        return SelfCache([None] * n_layers, [None] * n_layers)
+
+    @property
+    def length(self) -> int:
+        return 0 if self.k[0] is None else self.k[0].shape[2]
+
+
+def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, torch.Tensor], dims: Dims
+                    ) -> torch.Tensor:
+    """tokens [B,n] appended at positions cache.length.. ; returns logits [B,n,V] ([HF-M]:737-790, 1080).
+    n > 1 applies the causal mask among the new tokens."""
+    B, n = tokens.shape
+    H = dims.n_heads
+    hd = dims.d_model // H
+    p0 = cache.length
+    x = W["model.decoder.embed_tokens.weight"][tokens] + W["model.decoder.embed_positions.weight"][p0:p0 + n][None]
+    mask = None
+    if n > 1:
+        mask = torch.full((n, p0 + n), NEG_INF)
+        mask = torch.triu(mask, diagonal=p0 + 1)
+    for i in range(dims.dec_layers):
+        p = f"model.decoder.layers.{i}"
+        h = _ln(x, W[p + ".self_attn_layer_norm.weight"], W[p + ".self_attn_layer_norm.bias"])
+        q = _split_heads(_lin(h, W, p + ".self_attn.q_proj") * (hd ** -0.5), H)
+        k = _split_heads(_lin(h, W, p + ".self_attn.k_proj"), H)
+        v = _split_heads(_lin(h, W, p + ".self_attn.v_proj"), H)
+        if cache.k[i] is not None:
+            k = torch.cat([cache.k[i], k], dim=2)
+            v = torch.cat([cache.v[i], v], dim=2)
+        cache.k[i], cache.v[i] = k, v
+        x = x + _lin(_attend(q, k, v, mask), W, p + ".self_attn.out_proj")
+        h = _ln(x, W[p + ".encoder_attn_layer_norm.weight"], W[p + ".encoder_attn_layer_norm.bias"])
+        q = _split_heads(_lin(h, W, p + ".encoder_attn.q_proj") * (hd ** -0.5), H)
+        x = x + _lin(_attend(q, xkv[i][0], xkv[i][1]), W, p + ".encoder_attn.out_proj")
+        h = _ln(x, W[p + ".final_layer_norm.weight"], W[p + ".final_layer_norm.bias"])
+        x = x + _lin(_gelu(_lin(h, W, p + ".fc1")), W, p + ".fc2")
+    x = _ln(x, W["model.decoder.layer_norm.weight"], W["model.decoder.layer_norm.bias"])
+    return x @ W["model.decoder.embed_tokens.weight"].t()  # proj_out tied, [HF-M]:965,970
+
+
+# --------------------------------------------------------------------------------------------------
+# a10: logits processors + greedy selection
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class Rules:
+    """Static description of the processor stack ([HF-G]:1774-1812 order: begin-suppress, suppress,
+    timestamp rules)."""
+    eot: int
+    no_timestamps: int
+    timestamp_begin: int
+    suppress: Sequence[int] = ()
+    begin_suppress: Sequence[int] = ()
+    timestamps: bool = True            # WhisperTimeStampLogitsProcessor active
+    max_initial_timestamp_index: Optional[int] = 50
+    suppress_eot: bool = False         # benchmark mode: never stop
+
+
+def apply_rules(logits: torch.Tensor, sampled: Sequence[int], rules: Rules) -> torch.Tensor:
+    """One row f32[V] + the tokens sampled so far for that row (after the prompt) -> processed row.
+    [HF-LP]:1816 (begin suppress), :1869 (suppress), :2000-2047 (timestamp rules)."""
+    s = logits.clone().float()
+    n = len(sampled)
+    if n == 0 and len(rules.begin_suppress):
+        s[list(rules.begin_suppress)] = NEG_INF
+    if len(rules.suppress):
+        s[list(rules.suppress)] = NEG_INF
+    if rules.suppress_eot:
+        s[rules.eot] = NEG_INF
+    if rules.timestamps:
+        tb = rules.timestamp_begin
+        s[rules.no_timestamps] = NEG_INF
+        last_ts = n >= 1 and sampled[-1] >= tb
+        pen_ts = n < 2 or sampled[-2] >= tb
+        if last_ts:
+            if pen_ts:
+                s[tb:] = NEG_INF
+            else:
+                s[: rules.eot] = NEG_INF
+        ts = [t for t in sampled if t >= tb]
+        if ts:
+            last = ts[-1] if (last_ts and not pen_ts) else ts[-1] + 1
+            s[tb:last] = NEG_INF
+        if n == 0:
+            s[:tb] = NEG_INF
+            if rules.max_initial_timestamp_index is not None:
+                s[tb + rules.max_initial_timestamp_index + 1:] = NEG_INF
+        lp = torch.log_softmax(s, dim=-1)
+        if torch.logsumexp(lp[tb:], dim=-1) > lp[:tb].max():
+            s[:tb] = NEG_INF
+    return s
+
+
+@dataclass
+class GreedyResult:
+    tokens: List[List[int]]              # sampled tokens per clip (EOT included when emitted)
+    sum_logprob: List[float]
+    no_speech_prob: List[float]
+    step_logits: List[torch.Tensor] = field(default_factory=list)  # raw logits at each sampling step [B,V]
+
+
+def greedy_decode(enc: torch.Tensor, prompt: Sequence[int], W: Dict[str, torch.Tensor], dims: Dims,
+                  rules: Rules, max_new_tokens: int, no_speech_token: Optional[int] = None,
+                  sot_index: int = 0, keep_logits: bool = False, token_by_token_prompt: bool = True
+                  ) -> GreedyResult:
+    """Greedy search with the processor stack; every clip shares `prompt`.  The prompt is fed one token at
+    a time (exactly what the HIP engine does), which is arithmetically the same as a causal prefill.
+    no-speech probability = softmax of the raw logits at the <|startoftranscript|> position
+    ([HF-LP]:2050-2113)."""
+    B = enc.shape[0]
+    xkv = cross_kv(enc, W, dims)
+    cache = SelfCache.empty(dims.dec_layers)
+    no_speech = [0.0] * B
+    logits = None
+    if token_by_token_prompt:
+        for j, t in enumerate(prompt):
+            logits = decoder_forward(torch.full((B, 1), t, dtype=torch.long), cache, xkv, W, dims)[:, -1]
+            if no_speech_token is not None and j == sot_index:
+                no_speech = torch.softmax(logits.float(), dim=-1)[:, no_speech_token].tolist()
+    else:
+        full = decoder_forward(torch.tensor([list(prompt)] * B, dtype=torch.long), cache, xkv, W, dims)
+        logits = full[:, -1]
+        if no_speech_token is not None:
+            no_speech = torch.softmax(full[:, sot_index].float(), dim=-1)[:, no_speech_token].tolist()
+    sampled: List[List[int]] = [[] for _ in range(B)]
+    done = [False] * B
+    sum_lp = [0.0] * B
+    res = GreedyResult(sampled, sum_lp, no_speech)
+    for _ in range(max_new_tokens):
+        if keep_logits:
+            res.step_logits.append(logits.clone())
+        nxt = []
+        for b in range(B):
+            if done[b]:
+                nxt.append(rules.eot)
+                continue
+            s = apply_rules(logits[b], sampled[b], rules)
+            t = int(torch.argmax(s))
+            sum_lp[b] += float(torch.log_softmax(s, dim=-1)[t])
+            sampled[b].append(t)
+            if t == rules.eot:
+                done[b] = True
+            nxt.append(t)
+        if all(done) or cache.length >= dims.n_text_ctx:
+            break
+        logits = decoder_forward(torch.tensor(nxt, dtype=torch.long)[:, None], cache, xkv, W, dims)[:, -1]
+    return res
+
+
+def transcribe_tokens(pcm_batch: Sequence[np.ndarray], W: Dict[str, torch.Tensor], dims: Dims,
+                      prompt: Sequence[int], rules: Rules, max_new_tokens: int,
+                      no_speech_token: Optional[int] = None, sot_index: int = 0) -> GreedyResult:
+    """PCM -> token ids: the whole hot path (a5..a10) for one window per clip."""
+    n_samples = dims.n_audio_ctx * 2 * 160
+    mel = torch.from_numpy(np.stack([log_mel(p, dims.n_mels, n_samples) for p in pcm_batch]))
+    enc = encoder_forward(mel, W, dims)
+    return greedy_decode(enc, prompt, W, dims, rules, max_new_tokens, no_speech_token, sot_index)
