@@ -1,0 +1,141 @@
+/*
+ * ttasr.h - C ABI of the MI355X-native Whisper inference hot path (libttasr.so).
+ *
+ * Drop-in boundary.  The reference has no native FFI: its hot path is reached through the Python object
+ * faster_whisper.WhisperModel (constructor asr_core.py:141, api/file_asr.py:188,
+ * api/stt_streaming/src/asr/faster_whisper_asr.py:107-109; transcribe() asr_core.py:159-167,
+ * api/file_asr.py:457-465, faster_whisper_asr.py:170-172), which internally binds the CTranslate2 C++
+ * engine (ctranslate2.models.Whisper.encode / .generate).  The entry points below are what a binding
+ * for that pair of calls needs: everything from float32 PCM to token ids.  Plain pointers and sizes only;
+ * no torch / Python types.  INTEGRATION.md shows the ctypes stub on the reference side.
+ *
+ * Conventions: every function returns 0 on success, a negative TTASR_E_* otherwise, and never aborts the
+ * process; ttasr_last_error() gives the message.  A context is bound to one GPU and one HIP stream and is
+ * NOT re-entrant: one call in flight per context (the reference never issues concurrent transcribe()
+ * calls on one model: file_asr.py:175, streaming_asr.py:85-86).  All device memory (weights, paged KV
+ * pools, workspaces) is owned by the context from ttasr_create to ttasr_destroy.
+ * Pointers named *_host are caller-owned host buffers; `pcm` may be a host or device pointer as stated
+ * by `pcm_on_device`.
+ */
+#ifndef TTASR_H_
+#define TTASR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTASR_OK 0
+#define TTASR_E_INVALID (-1)   /* bad argument / wrong call order */
+#define TTASR_E_HIP (-2)       /* HIP runtime error (message holds hipGetErrorString) */
+#define TTASR_E_NOMEM (-3)
+#define TTASR_E_WEIGHTS (-4)   /* unknown / missing / mis-shaped tensor */
+
+#define TTASR_COMPUTE_F32 0    /* f32 weights+activations, exact-f32 MFMA: the 1e-3 parity mode */
+#define TTASR_COMPUTE_BF16 1   /* bf16 weights+activations, f32 accumulate/LN/softmax: throughput mode */
+
+typedef struct ttasr_ctx ttasr_ctx;
+
+/* Model geometry (what CTranslate2 reads from config.json / model.bin of the `models/` directory,
+ * faster_whisper_asr.py:38) plus engine sizing. */
+typedef struct ttasr_config {
+  int32_t n_mels;       /* 80 (tiny..large-v2) or 128 (large-v3) */
+  int32_t n_audio_ctx;  /* encoder positions, 1500; mel frames per window = 2 * n_audio_ctx */
+  int32_t d_model;
+  int32_t n_heads;      /* head_dim = d_model / n_heads must be 64 */
+  int32_t ffn_dim;
+  int32_t enc_layers;
+  int32_t dec_layers;
+  int32_t vocab;
+  int32_t n_text_ctx;   /* 448 */
+  int32_t compute_type; /* TTASR_COMPUTE_* */
+  int32_t max_batch;    /* largest B any call will use; sizes the KV pools and workspaces */
+  int32_t reserved;
+} ttasr_config;
+
+/* Decoding rules: the logits-processor stack of the reference path (CTranslate2 generate() options
+ * suppress_blank / suppress_tokens / max_initial_timestamp_index; same rules as HF
+ * generation/logits_process.py:1816,1869,1909-2047). */
+typedef struct ttasr_gen_opts {
+  int32_t max_new_tokens;
+  int32_t eot;
+  int32_t no_timestamps;
+  int32_t timestamp_begin;
+  int32_t no_speech;                   /* token id, or -1: do not compute no-speech probability */
+  int32_t sot_index;                   /* prompt position of <|startoftranscript|> */
+  int32_t timestamps;                  /* 1: apply the timestamp rules */
+  int32_t max_initial_timestamp_index; /* -1: none */
+  int32_t suppress_eot;                /* 1: fixed-length decode (benchmark mode) */
+  int32_t n_suppress;
+  int32_t n_begin_suppress;
+  int32_t check_interval;              /* host polls "all rows finished" every this many steps (>=1) */
+  const int32_t* suppress;             /* host, n_suppress ids masked at every step */
+  const int32_t* begin_suppress;       /* host, n_begin_suppress ids masked at the first sampled position */
+} ttasr_gen_opts;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx);
+void ttasr_destroy(ttasr_ctx* ctx);
+/* Message of the last failing call on this context (ctx == NULL: last ttasr_create failure). */
+const char* ttasr_last_error(const ttasr_ctx* ctx);
+/* Version / build string, e.g. "ttasr 0.1 gfx950". */
+const char* ttasr_version(void);
+
+/* ---- weights (replaces WhisperModel.__init__'s model.bin load) ---------------------------------- */
+/* One tensor, float32 host data, HF state-dict name (model.encoder.conv1.weight, ...).  The engine
+ * converts to its device layout (bf16 cast, QKV fusion, conv tap re-ordering, q pre-scaling by 1/8). */
+int ttasr_load_tensor(ttasr_ctx* ctx, const char* name, const float* data_host, const int64_t* dims, int32_t ndim);
+/* Checks every tensor arrived; must precede any compute call. */
+int ttasr_finalize_weights(ttasr_ctx* ctx);
+
+/* ---- a5: log-mel front end ----------------------------------------------------------------------- */
+/* pcm: B clips, clip b at pcm + b*pcm_stride, n_samples[b] valid samples (zero-padded / trimmed to one
+ * window = 2*n_audio_ctx*160 samples).  Result stays resident for ttasr_encode; if out_mel_host != NULL
+ * it also receives float32 [B][n_mels][2*n_audio_ctx]. */
+int ttasr_log_mel(ttasr_ctx* ctx, const float* pcm, int64_t pcm_stride, const int64_t* n_samples_host, int32_t B,
+                  int32_t pcm_on_device, float* out_mel_host);
+/* Test hook: place a caller-computed mel [B][n_mels][2*n_audio_ctx] as the encoder input. */
+int ttasr_set_mel(ttasr_ctx* ctx, const float* mel_host, int32_t B);
+
+/* ---- a6-a8: encoder + cross-attention K/V (ctranslate2 Whisper.encode) ------------------------- */
+/* Runs the conv stem, the encoder stack and the per-decoder-layer cross K/V projection for the B clips
+ * whose mel is resident.  out_enc_host (optional) receives float32 [B][n_audio_ctx][d_model]. */
+int ttasr_encode(ttasr_ctx* ctx, int32_t B, float* out_enc_host);
+/* Test hooks. */
+int ttasr_set_encoder_output(ttasr_ctx* ctx, const float* enc_host, int32_t B); /* then builds cross K/V */
+int ttasr_get_cross_kv(ttasr_ctx* ctx, int32_t layer, int32_t which /*0 K, 1 V*/, int32_t B, float* out_host /*[B][H][T][64]*/);
+
+/* ---- a9-a10: decoder (ctranslate2 Whisper.generate) --------------------------------------------- */
+/* Greedy search.  prompt_host: [B][max_prompt] ids, prompt_len_host[b] of them valid (>=1).
+ * out_tokens_host: [B][max_new_tokens] sampled ids (EOT included when emitted), out_len_host[b] count.
+ * out_sum_logprob_host / out_no_speech_host: optional [B]. */
+int ttasr_generate(ttasr_ctx* ctx, int32_t B, const int32_t* prompt_host, const int32_t* prompt_len_host,
+                   int32_t max_prompt, const ttasr_gen_opts* opts, int32_t* out_tokens_host, int32_t* out_len_host,
+                   float* out_sum_logprob_host, float* out_no_speech_host);
+/* Step-level access for parity tests: reset the self-attention cache, then feed one token per row per
+ * call; logits_host (optional) receives raw float32 [B][vocab] for the position just fed. */
+int ttasr_decode_reset(ttasr_ctx* ctx, int32_t B);
+int ttasr_decode_step(ttasr_ctx* ctx, const int32_t* tokens_host, int32_t B, float* logits_host);
+/* Known-answer hook for the rule kernel alone: rows [n][vocab] raw logits, hist [n][hist_stride]
+ * sampled-token histories padded with -1 -> processed rows (masked entries = -inf) and the selected id. */
+int ttasr_apply_rules(ttasr_ctx* ctx, const float* rows_host, const int32_t* hist_host, int32_t hist_stride,
+                      int32_t n, const ttasr_gen_opts* opts, float* out_rows_host, int32_t* out_choice_host);
+
+/* ---- measurement --------------------------------------------------------------------------------- */
+/* hipEvent times (ms) of the last log_mel / encode (stem+layers, cross-KV) / generate calls:
+ * out[0]=mel out[1]=encoder out[2]=cross_kv out[3]=decode. */
+int ttasr_phase_ms(ttasr_ctx* ctx, float out_ms[4]);
+/* Re-launches one named hot kernel `iters` times on the context's stream with the state left by the
+ * last encode/generate (B clips) and returns its average duration measured with hipEvents, plus the
+ * algorithmic bytes and flops one launch moves/does.  Names: "xattn" (decoder cross-attention),
+ * "enc_gemm_fc1", "enc_attn", "dec_gemm_fc1", "logits_gemm". */
+int ttasr_bench_kernel(ttasr_ctx* ctx, const char* name, int32_t B, int32_t iters, float* out_avg_ms,
+                       double* out_bytes_per_launch, double* out_flops_per_launch);
+/* Device-wide synchronisation of the context's stream. */
+int ttasr_sync(ttasr_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTASR_H_ */

@@ -1,0 +1,123 @@
+// Shared device helpers and kernel-launcher declarations for libttasr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all conversions are explicit below
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- GEMM epilogue description (shared by every GEMM flavour) ------------------------------------
+// C[m][n] = act(alpha-free acc + bias[n]) (+ rowtab[(m % rowmod)][n]) (+ residual[m][n]); written as f32
+// and/or T.  headsplit != 0 scatters T output into the cross-KV layout [which][b][h][t][64].
+struct GemmEpi {
+  const float* bias = nullptr;      // [N]
+  int act = 0;                      // 0 none, 1 exact-erf GELU
+  const float* rowtab = nullptr;    // [rowmod][N] f32 (encoder positions)
+  int rowmod = 0;
+  const float* residual = nullptr;  // f32 [M][ldc] (may alias out_f32)
+  float* out_f32 = nullptr;         // f32 [M][ldc]
+  void* out_t = nullptr;            // T   [M][ldc] (or head-split)
+  int64_t ldc = 0;
+  int64_t batch_stride_c = 0;       // elements, applied to residual/out_f32/out_t per blockIdx.z
+  int headsplit = 0;                // 1: out_t index = which*hs_which + ((b*H+h)*T + t)*64 + j
+  int hs_T = 0, hs_H = 0, hs_d = 0;
+  int64_t hs_which = 0;
+};
+
+struct GemmArgs {
+  const void* A = nullptr;  // T [M][lda] (rows may overlap: conv-as-GEMM)
+  const void* W = nullptr;  // T [N][ldw]
+  int M = 0, N = 0, K = 0;
+  int64_t lda = 0, ldw = 0;
+  int64_t batch_stride_a = 0;
+  int batch = 1;
+  GemmEpi epi;
+};
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------------------
+template <typename T> void launch_gemm_basic(const GemmArgs& g, hipStream_t s);
+void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s);  // requires M%128==0? no: see kernels_gemm.hip
+bool gemm_bf16_fast_ok(const GemmArgs& g);
+
+template <typename T>
+void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
+
+// mel
+void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
+                const float* filters /*[201][n_mels]*/, const float* dft_cos, const float* dft_sin /*[400]*/,
+                const float* window /*[400]*/, float* logmel /*[B][n_mels][n_frames]*/, unsigned* clip_max /*[B]*/,
+                hipStream_t s);
+template <typename T>
+void launch_mel_finish(float* logmel, const unsigned* clip_max, T* mel_t /*[B][n_frames+2][n_mels]*/, int B, int n_mels,
+                       int n_frames, hipStream_t s);
+template <typename T>
+void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s);
+
+// encoder attention over fused qkv [B*T][3d] -> out [B*T][d]
+template <typename T> void launch_enc_attn_simple(const T* qkv, T* out, int B, int T_, int H, hipStream_t s);
+void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s);
+
+// decoder
+struct DecState {            // device-resident per-row search state
+  int32_t* cur_tok;          // [B] token fed at this step
+  int32_t* step;             // [1] position of cur_tok
+  int32_t* n_sampled;        // [B]
+  int32_t* last_tok;         // [B] last sampled (or -1)
+  int32_t* pen_tok;          // [B] penultimate sampled (or -1)
+  int32_t* last_ts;          // [B] most recent timestamp token sampled (or -1)
+  int32_t* done;             // [B]
+  int32_t* n_done;           // [1]
+  float* sum_logprob;        // [B]
+  float* no_speech;          // [B]
+  int32_t* out_tokens;       // [B][max_new]
+  const int32_t* prompt;     // [B][max_prompt]
+  const int32_t* prompt_len; // [B]
+  const uint8_t* mask;       // [V] bit0 suppress, bit1 begin-suppress
+};
+struct RuleParams {
+  int V, ldv, max_prompt, max_new;
+  int eot, no_timestamps, timestamp_begin, no_speech, sot_index, timestamps, max_initial, suppress_eot;
+};
+template <typename T>
+void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
+template <typename T>
+void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
+                             int64_t pool_layer_off, const int32_t* step, T* out /*[B][d]*/, int B, int H, hipStream_t s);
+template <typename T>
+void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B][H][Tk][64]*/, T* out, int B, int H,
+                              int Tk, hipStream_t s);
+void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows /*nullable*/, hipStream_t s);
+void launch_advance(int32_t* step, hipStream_t s);
+template <typename T> void launch_cast(const float* in, T* out, int64_t n, hipStream_t s);
+template <typename T> void launch_uncast(const T* in, float* out, int64_t n, hipStream_t s);

@@ -1,0 +1,850 @@
+// libttasr host side: context, weight intake, workspaces, the encode / decode schedules and the C ABI
+// declared in include/ttasr.h.  One context = one GPU = one HIP stream; no hidden CPU fallback: every
+// compute entry point launches the HIP kernels of this directory or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ttasr.h"
+#include "common.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Slot {              // where one named tensor lands on the device
+  void* dst = nullptr;     // T* (matrix kinds) or float* (vector kinds)
+  int64_t rows = 0, cols = 0;
+  int kind = 0;            // 0 matrix->T, 1 vector->f32, 2 conv [out][in][3] -> T [out][3][in], 3 f32 matrix
+  float scale = 1.0f;
+  bool loaded = false;
+};
+
+struct EncLayerW { float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *b1, *b2; void *wqkv, *wo, *w1, *w2; };
+struct DecLayerW {
+  float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *bqx, *bkvx, *box, *ln3g, *ln3b, *b1, *b2;
+  void *wqkv, *wo, *wqx, *wkvx, *wox, *w1, *w2;
+};
+
+}  // namespace
+
+struct ttasr_ctx {
+  ttasr_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool bf16 = false;
+  bool finalized = false;
+  bool force_basic = false;
+  bool use_graph = true;
+  size_t esz = 4;  // sizeof(T)
+  int T = 0, F = 0, d = 0, H = 0, ffn = 0, V = 0, ldv = 0, M = 0, maxB = 0, n_samples = 0;
+  int pages_per_seq = 0;
+  std::vector<void*> allocs;
+  std::unordered_map<std::string, Slot> slots;
+
+  // weights
+  void *conv1_w = nullptr, *conv2_w = nullptr, *emb = nullptr, *dpos = nullptr;
+  float *conv1_b = nullptr, *conv2_b = nullptr, *epos = nullptr, *elnf_g = nullptr, *elnf_b = nullptr, *dlnf_g = nullptr,
+        *dlnf_b = nullptr;
+  std::vector<EncLayerW> enc;
+  std::vector<DecLayerW> dec;
+  float* stage_f32 = nullptr;  // upload staging
+  size_t stage_elems = 0;
+
+  // mel constants
+  float *filters = nullptr, *dcos = nullptr, *dsin = nullptr, *window = nullptr;
+
+  // workspaces
+  float* pcm_dev = nullptr; int64_t* nsamp_dev = nullptr; unsigned* clip_max = nullptr;
+  float* mel = nullptr; void* mel_t = nullptr; void* c1 = nullptr;
+  float* x = nullptr; void *h = nullptr, *qkv = nullptr, *att = nullptr, *mid = nullptr, *enc_out = nullptr;
+  void* xkv = nullptr; int64_t xkv_layer_elems = 0, xkv_which_elems = 0;
+  void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
+  float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
+  float* rows_out = nullptr;
+  DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
+  int32_t* pinned_i32 = nullptr;  // host pinned scratch
+  int max_new_alloc = 0, max_prompt_alloc = 0;
+
+  int B_mel = 0, B_enc = 0, B_dec = 0;
+  hipEvent_t ev[8]{};
+  float phase_ms[4]{0, 0, 0, 0};
+
+  // decode-step graphs keyed by (B, with_logits)
+  struct GraphKey { int B; int mode; hipGraphExec_t exec; };
+  std::vector<GraphKey> graphs;
+  RuleParams rp{};
+};
+
+namespace {
+
+int fail(ttasr_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                                       \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return fail((c), TTASR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                                    \
+  } while (0)
+
+template <typename P>
+int dalloc(ttasr_ctx* c, P** p, size_t bytes, bool zero = true) {
+  void* q = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  c->allocs.push_back(q);
+  if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
+  *p = (P*)q;
+  return 0;
+}
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+
+// slaney mel filter bank, same construction as the oracle's mel_filter_bank (float64, cast to f32)
+double hz2mel(double f) {
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel2hz(double m) {
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+std::vector<float> mel_filters(int n_mels) {
+  const int nf = 201;
+  std::vector<double> hz(n_mels + 2);
+  const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
+  for (int i = 0; i < n_mels + 2; ++i) hz[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
+  std::vector<float> fb((size_t)nf * n_mels);
+  for (int k = 0; k < nf; ++k) {
+    double f = 8000.0 * k / (nf - 1);
+    for (int m = 0; m < n_mels; ++m) {
+      double down = -(hz[m] - f) / (hz[m + 1] - hz[m]);
+      double up = (hz[m + 2] - f) / (hz[m + 2] - hz[m + 1]);
+      double w = std::max(0.0, std::min(down, up)) * 2.0 / (hz[m + 2] - hz[m]);
+      fb[(size_t)k * n_mels + m] = (float)w;
+    }
+  }
+  return fb;
+}
+
+void add_slot(ttasr_ctx* c, const std::string& name, void* dst, int64_t rows, int64_t cols, int kind, float scale = 1.f) {
+  Slot s; s.dst = dst; s.rows = rows; s.cols = cols; s.kind = kind; s.scale = scale;
+  c->slots[name] = s;
+}
+
+int alloc_mat(ttasr_ctx* c, void** p, int64_t elems) { return dalloc(c, (char**)p, (size_t)elems * c->esz); }
+int alloc_vec(ttasr_ctx* c, float** p, int64_t elems) { return dalloc(c, p, (size_t)elems * 4); }
+
+int build_weights(ttasr_ctx* c) {
+  const int d = c->d, F = c->ffn, M = c->M, V = c->V;
+  const size_t e = c->esz;
+  auto off = [&](void* base, int64_t elems) { return (void*)((char*)base + (size_t)elems * e); };
+  TRY(alloc_mat(c, &c->conv1_w, (int64_t)d * 3 * M)); TRY(alloc_vec(c, &c->conv1_b, d));
+  TRY(alloc_mat(c, &c->conv2_w, (int64_t)d * 3 * d)); TRY(alloc_vec(c, &c->conv2_b, d));
+  TRY(alloc_vec(c, &c->epos, (int64_t)c->T * d));
+  add_slot(c, "model.encoder.conv1.weight", c->conv1_w, d, 3 * M, 2);
+  add_slot(c, "model.encoder.conv1.bias", c->conv1_b, d, 1, 1);
+  add_slot(c, "model.encoder.conv2.weight", c->conv2_w, d, 3 * d, 2);
+  add_slot(c, "model.encoder.conv2.bias", c->conv2_b, d, 1, 1);
+  add_slot(c, "model.encoder.embed_positions.weight", c->epos, c->T, d, 3);
+  auto ln = [&](const std::string& p, float** g, float** b) -> int {
+    TRY(alloc_vec(c, g, d)); TRY(alloc_vec(c, b, d));
+    add_slot(c, p + ".weight", *g, d, 1, 1); add_slot(c, p + ".bias", *b, d, 1, 1);
+    return 0;
+  };
+  // fused q|k|v: rows [0,d) = q (pre-scaled by head_dim^-0.5 = 1/8, exact in f32 and bf16;
+  // HF modeling_whisper.py:309 scales the q_proj output), [d,2d) = k (no bias, :279), [2d,3d) = v
+  auto attn_fused = [&](const std::string& p, void** wqkv, float** bqkv) -> int {
+    TRY(alloc_mat(c, wqkv, (int64_t)3 * d * d)); TRY(alloc_vec(c, bqkv, 3 * d));
+    add_slot(c, p + ".q_proj.weight", *wqkv, d, d, 0, 0.125f);
+    add_slot(c, p + ".q_proj.bias", *bqkv, d, 1, 1, 0.125f);
+    add_slot(c, p + ".k_proj.weight", off(*wqkv, (int64_t)d * d), d, d, 0);
+    add_slot(c, p + ".v_proj.weight", off(*wqkv, (int64_t)2 * d * d), d, d, 0);
+    add_slot(c, p + ".v_proj.bias", *bqkv + 2 * d, d, 1, 1);
+    return 0;
+  };
+  auto lin = [&](const std::string& p, void** w, float** b, int64_t n_out, int64_t n_in) -> int {
+    TRY(alloc_mat(c, w, n_out * n_in)); TRY(alloc_vec(c, b, n_out));
+    add_slot(c, p + ".weight", *w, n_out, n_in, 0); add_slot(c, p + ".bias", *b, n_out, 1, 1);
+    return 0;
+  };
+  c->enc.resize(c->cfg.enc_layers);
+  for (int i = 0; i < c->cfg.enc_layers; ++i) {
+    std::string p = "model.encoder.layers." + std::to_string(i);
+    EncLayerW& L = c->enc[i];
+    TRY(ln(p + ".self_attn_layer_norm", &L.ln1g, &L.ln1b));
+    TRY(attn_fused(p + ".self_attn", &L.wqkv, &L.bqkv));
+    TRY(lin(p + ".self_attn.out_proj", &L.wo, &L.bo, d, d));
+    TRY(ln(p + ".final_layer_norm", &L.ln2g, &L.ln2b));
+    TRY(lin(p + ".fc1", &L.w1, &L.b1, F, d));
+    TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
+  }
+  TRY(ln("model.encoder.layer_norm", &c->elnf_g, &c->elnf_b));
+  TRY(alloc_mat(c, &c->emb, (int64_t)V * d));
+  TRY(alloc_mat(c, &c->dpos, (int64_t)c->cfg.n_text_ctx * d));
+  add_slot(c, "model.decoder.embed_tokens.weight", c->emb, V, d, 0);
+  add_slot(c, "model.decoder.embed_positions.weight", c->dpos, c->cfg.n_text_ctx, d, 0);
+  c->dec.resize(c->cfg.dec_layers);
+  for (int i = 0; i < c->cfg.dec_layers; ++i) {
+    std::string p = "model.decoder.layers." + std::to_string(i);
+    DecLayerW& L = c->dec[i];
+    TRY(ln(p + ".self_attn_layer_norm", &L.ln1g, &L.ln1b));
+    TRY(attn_fused(p + ".self_attn", &L.wqkv, &L.bqkv));
+    TRY(lin(p + ".self_attn.out_proj", &L.wo, &L.bo, d, d));
+    TRY(ln(p + ".encoder_attn_layer_norm", &L.ln2g, &L.ln2b));
+    TRY(alloc_mat(c, &L.wqx, (int64_t)d * d)); TRY(alloc_vec(c, &L.bqx, d));
+    add_slot(c, p + ".encoder_attn.q_proj.weight", L.wqx, d, d, 0, 0.125f);
+    add_slot(c, p + ".encoder_attn.q_proj.bias", L.bqx, d, 1, 1, 0.125f);
+    TRY(alloc_mat(c, &L.wkvx, (int64_t)2 * d * d)); TRY(alloc_vec(c, &L.bkvx, 2 * d));
+    add_slot(c, p + ".encoder_attn.k_proj.weight", L.wkvx, d, d, 0);
+    add_slot(c, p + ".encoder_attn.v_proj.weight", off(L.wkvx, (int64_t)d * d), d, d, 0);
+    add_slot(c, p + ".encoder_attn.v_proj.bias", L.bkvx + d, d, 1, 1);
+    TRY(lin(p + ".encoder_attn.out_proj", &L.wox, &L.box, d, d));
+    TRY(ln(p + ".final_layer_norm", &L.ln3g, &L.ln3b));
+    TRY(lin(p + ".fc1", &L.w1, &L.b1, F, d));
+    TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
+  }
+  TRY(ln("model.decoder.layer_norm", &c->dlnf_g, &c->dlnf_b));
+  c->stage_elems = std::max<size_t>((size_t)V * d, (size_t)d * 3 * d);
+  c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)F * d);
+  TRY(dalloc(c, &c->stage_f32, c->stage_elems * 4, false));
+  return 0;
+}
+
+int build_workspaces(ttasr_ctx* c) {
+  const int64_t B = c->maxB, T = c->T, F = c->F, d = c->d, M = c->M, H = c->H;
+  TRY(dalloc(c, &c->pcm_dev, (size_t)B * c->n_samples * 4));
+  TRY(dalloc(c, &c->nsamp_dev, (size_t)B * 8));
+  TRY(dalloc(c, &c->clip_max, (size_t)B * 4));
+  TRY(dalloc(c, &c->mel, (size_t)B * M * F * 4));
+  TRY(alloc_mat(c, &c->mel_t, B * (F + 2) * M));
+  TRY(alloc_mat(c, &c->c1, B * (F + 2) * d));
+  TRY(dalloc(c, &c->x, (size_t)B * T * d * 4));
+  TRY(alloc_mat(c, &c->h, B * T * d));
+  TRY(alloc_mat(c, &c->qkv, B * T * 3 * d));
+  TRY(alloc_mat(c, &c->att, B * T * d));
+  TRY(alloc_mat(c, &c->mid, B * T * c->ffn));
+  TRY(alloc_mat(c, &c->enc_out, B * T * d));
+  c->xkv_which_elems = B * H * T * 64;
+  c->xkv_layer_elems = 2 * c->xkv_which_elems;
+  TRY(alloc_mat(c, &c->xkv, c->xkv_layer_elems * c->cfg.dec_layers));
+  c->pages_per_seq = (c->cfg.n_text_ctx + 15) / 16;
+  const int64_t n_pages = B * c->pages_per_seq;
+  c->pool_layer_elems = n_pages * 2 * H * 16 * 64;
+  TRY(alloc_mat(c, &c->pool, c->pool_layer_elems * c->cfg.dec_layers));
+  TRY(dalloc(c, &c->page_table, (size_t)n_pages * 4));
+  std::vector<int32_t> pt(n_pages);
+  for (int64_t i = 0; i < n_pages; ++i) pt[i] = (int32_t)i;  // identity: row b owns pages [b*pps, (b+1)*pps)
+  HIPCHK(c, hipMemcpyAsync(c->page_table, pt.data(), n_pages * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  TRY(dalloc(c, &c->dx, (size_t)B * d * 4));
+  TRY(alloc_mat(c, &c->dh, B * d));
+  TRY(alloc_mat(c, &c->dqkv, B * 3 * d));
+  TRY(alloc_mat(c, &c->dq, B * d));
+  TRY(alloc_mat(c, &c->datt, B * d));
+  TRY(alloc_mat(c, &c->dmid, B * c->ffn));
+  TRY(dalloc(c, &c->logits, (size_t)B * c->ldv * 4));
+  c->max_new_alloc = c->cfg.n_text_ctx;
+  c->max_prompt_alloc = c->cfg.n_text_ctx;
+  TRY(dalloc(c, &c->st.cur_tok, B * 4)); TRY(dalloc(c, &c->st.step, 16)); TRY(dalloc(c, &c->st.n_sampled, B * 4));
+  TRY(dalloc(c, &c->st.last_tok, B * 4)); TRY(dalloc(c, &c->st.pen_tok, B * 4)); TRY(dalloc(c, &c->st.last_ts, B * 4));
+  TRY(dalloc(c, &c->st.done, B * 4)); TRY(dalloc(c, &c->st.n_done, 16)); TRY(dalloc(c, &c->st.sum_logprob, B * 4));
+  TRY(dalloc(c, &c->st.no_speech, B * 4)); TRY(dalloc(c, &c->st.out_tokens, (size_t)B * c->max_new_alloc * 4));
+  TRY(dalloc(c, &c->prompt_dev, (size_t)B * c->max_prompt_alloc * 4)); TRY(dalloc(c, &c->plen_dev, B * 4));
+  TRY(dalloc(c, &c->mask_dev, (size_t)c->V + 16));
+  c->st.mask = c->mask_dev;
+  HIPCHK(c, hipHostMalloc((void**)&c->pinned_i32, 4096));
+  // mel constants
+  std::vector<float> fb = mel_filters(c->M), cs(400), sn(400), wn(400);
+  for (int i = 0; i < 400; ++i) {
+    cs[i] = (float)std::cos(2.0 * M_PI * i / 400.0);
+    sn[i] = (float)std::sin(2.0 * M_PI * i / 400.0);
+    wn[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
+  }
+  TRY(dalloc(c, &c->filters, fb.size() * 4)); TRY(dalloc(c, &c->dcos, 1600)); TRY(dalloc(c, &c->dsin, 1600));
+  TRY(dalloc(c, &c->window, 1600));
+  HIPCHK(c, hipMemcpyAsync(c->filters, fb.data(), fb.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->dcos, cs.data(), 1600, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->dsin, sn.data(), 1600, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->window, wn.data(), 1600, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
+  return 0;
+}
+
+// ---- typed schedules ------------------------------------------------------------------------------
+template <typename T>
+void gemm(ttasr_ctx* c, const GemmArgs& g) {
+  if constexpr (sizeof(T) == 2) {
+    if (!c->force_basic && g.M >= 256 && gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->stream); return; }
+  }
+  launch_gemm_basic<T>(g, c->stream);
+}
+
+template <typename T>
+GemmArgs lin_args(const void* A, const void* W, int M, int N, int K) {
+  GemmArgs g; g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.epi.ldc = N;
+  return g;
+}
+
+template <typename T>
+int run_cross_kv(ttasr_ctx* c, int B) {
+  const int d = c->d, T_ = c->T;
+  for (int l = 0; l < c->cfg.dec_layers; ++l) {
+    GemmArgs g = lin_args<T>(c->enc_out, c->dec[l].wkvx, B * T_, 2 * d, d);
+    g.epi.bias = c->dec[l].bkvx;
+    g.epi.out_t = (char*)c->xkv + (size_t)l * c->xkv_layer_elems * c->esz;
+    g.epi.headsplit = 1; g.epi.hs_T = T_; g.epi.hs_H = c->H; g.epi.hs_d = d; g.epi.hs_which = c->xkv_which_elems;
+    gemm<T>(c, g);
+  }
+  return 0;
+}
+
+template <typename T>
+int run_encoder(ttasr_ctx* c, int B) {
+  const int d = c->d, T_ = c->T, F = c->F, M = c->M, ffn = c->ffn;
+  hipStream_t s = c->stream;
+  hipEventRecord(c->ev[2], s);
+  {  // conv1 as GEMM over the zero-padded time-major mel image: row t of A = rows t..t+2 of the image
+    GemmArgs g; g.A = c->mel_t; g.W = c->conv1_w; g.M = F; g.N = d; g.K = 3 * M; g.lda = M; g.ldw = 3 * M;
+    g.batch = B; g.batch_stride_a = (int64_t)(F + 2) * M;
+    g.epi.bias = c->conv1_b; g.epi.act = 1; g.epi.out_t = (char*)c->c1 + (size_t)d * c->esz; g.epi.ldc = d;
+    g.epi.batch_stride_c = (int64_t)(F + 2) * d;
+    gemm<T>(c, g);
+  }
+  {  // conv2 (stride 2): row t of A starts at padded row 2t; epilogue adds the sinusoid positions
+    GemmArgs g; g.A = c->c1; g.W = c->conv2_w; g.M = T_; g.N = d; g.K = 3 * d; g.lda = 2 * d; g.ldw = 3 * d;
+    g.batch = B; g.batch_stride_a = (int64_t)(F + 2) * d;
+    g.epi.bias = c->conv2_b; g.epi.act = 1; g.epi.rowtab = c->epos; g.epi.rowmod = T_; g.epi.out_f32 = c->x;
+    g.epi.ldc = d; g.epi.batch_stride_c = (int64_t)T_ * d;
+    gemm<T>(c, g);
+  }
+  const int R = B * T_;
+  for (int l = 0; l < c->cfg.enc_layers; ++l) {
+    const EncLayerW& L = c->enc[l];
+    launch_layernorm<T>(c->x, L.ln1g, L.ln1b, (T*)c->h, R, d, s);
+    { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
+    if (sizeof(T) == 2 && !c->force_basic && getenv("TTASR_FLASH") != nullptr)
+      launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
+    else
+      launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
+    { GemmArgs g = lin_args<T>(c->att, L.wo, R, d, d); g.epi.bias = L.bo; g.epi.residual = c->x; g.epi.out_f32 = c->x; gemm<T>(c, g); }
+    launch_layernorm<T>(c->x, L.ln2g, L.ln2b, (T*)c->h, R, d, s);
+    { GemmArgs g = lin_args<T>(c->h, L.w1, R, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->mid; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->mid, L.w2, R, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->x; g.epi.out_f32 = c->x; gemm<T>(c, g); }
+  }
+  launch_layernorm<T>(c->x, c->elnf_g, c->elnf_b, (T*)c->enc_out, R, d, s);
+  hipEventRecord(c->ev[3], s);
+  run_cross_kv<T>(c, B);
+  hipEventRecord(c->ev[4], s);
+  return 0;
+}
+
+// One decoder step for B rows at position *st.step.  mode 0: through logits + select; 1: logits only
+// (test API); 2: no logits (all rows forced by the prompt), select just advances the forced token.
+template <typename T>
+void run_decode_step(ttasr_ctx* c, int B, int mode) {
+  const int d = c->d, ffn = c->ffn;
+  hipStream_t s = c->stream;
+  launch_embed<T>(c->st.cur_tok, c->st.step, (const T*)c->emb, (const T*)c->dpos, c->dx, B, d, s);
+  for (int l = 0; l < c->cfg.dec_layers; ++l) {
+    const DecLayerW& L = c->dec[l];
+    launch_layernorm<T>(c->dx, L.ln1g, L.ln1b, (T*)c->dh, B, d, s);
+    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv; gemm<T>(c, g); }
+    launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
+                               (int64_t)l * c->pool_layer_elems, c->st.step, (T*)c->datt, B, c->H, s);
+    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+    launch_layernorm<T>(c->dx, L.ln2g, L.ln2b, (T*)c->dh, B, d, s);
+    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq; gemm<T>(c, g); }
+    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
+    launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, s);
+    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+    launch_layernorm<T>(c->dx, L.ln3g, L.ln3b, (T*)c->dh, B, d, s);
+    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+  }
+  if (mode != 2) {
+    launch_layernorm<T>(c->dx, c->dlnf_g, c->dlnf_b, (T*)c->dh, B, d, s);
+    GemmArgs g = lin_args<T>(c->dh, c->emb, B, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
+    g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
+    gemm<T>(c, g);
+  }
+  if (mode != 1) launch_select(c->logits, c->st, c->rp, B, nullptr, s);
+  launch_advance(c->st.step, s);
+}
+
+int step_graph(ttasr_ctx* c, int B, int mode) {
+  if (!c->use_graph) {
+    if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
+    return 0;
+  }
+  for (auto& g : c->graphs)
+    if (g.B == B && g.mode == mode) { HIPCHK(c, hipGraphLaunch(g.exec, c->stream)); return 0; }
+  hipGraph_t graph;
+  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
+  HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+  hipGraphExec_t exec;
+  HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipGraphDestroy(graph);
+  c->graphs.push_back({B, mode, exec});
+  HIPCHK(c, hipGraphLaunch(exec, c->stream));
+  return 0;
+}
+
+int check_ready(ttasr_ctx* c, int B) {
+  if (!c) return TTASR_E_INVALID;
+  if (!c->finalized) return fail(c, TTASR_E_INVALID, "weights not finalized (call ttasr_finalize_weights first)");
+  if (B < 1 || B > c->maxB) return fail(c, TTASR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, c->maxB);
+  HIPCHK(c, hipSetDevice(c->device));
+  return 0;
+}
+
+int upload_rules(ttasr_ctx* c, const ttasr_gen_opts* o, int max_prompt) {
+  if (!o) return fail(c, TTASR_E_INVALID, "opts is NULL");
+  if (o->max_new_tokens < 1 || o->max_new_tokens > c->max_new_alloc)
+    return fail(c, TTASR_E_INVALID, "max_new_tokens %d outside [1, %d]", o->max_new_tokens, c->max_new_alloc);
+  std::vector<uint8_t> mask(c->V, 0);
+  for (int i = 0; i < o->n_suppress; ++i) {
+    int t = o->suppress[i];
+    if (t < 0 || t >= c->V) return fail(c, TTASR_E_INVALID, "suppress id %d outside vocabulary", t);
+    mask[t] |= 1;
+  }
+  for (int i = 0; i < o->n_begin_suppress; ++i) {
+    int t = o->begin_suppress[i];
+    if (t < 0 || t >= c->V) return fail(c, TTASR_E_INVALID, "begin_suppress id %d outside vocabulary", t);
+    mask[t] |= 2;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->mask_dev, mask.data(), c->V, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  RuleParams& rp = c->rp;
+  rp.V = c->V; rp.ldv = c->ldv; rp.max_prompt = max_prompt; rp.max_new = o->max_new_tokens;
+  rp.eot = o->eot; rp.no_timestamps = o->no_timestamps; rp.timestamp_begin = o->timestamp_begin;
+  rp.no_speech = o->no_speech; rp.sot_index = o->sot_index; rp.timestamps = o->timestamps;
+  rp.max_initial = o->max_initial_timestamp_index; rp.suppress_eot = o->suppress_eot;
+  if (rp.eot < 0 || rp.eot >= c->V || rp.timestamp_begin < 0 || rp.timestamp_begin > c->V)
+    return fail(c, TTASR_E_INVALID, "special token ids outside vocabulary");
+  return 0;
+}
+
+void drop_graphs(ttasr_ctx* c) {
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
+  c->graphs.clear();
+}
+
+int reset_search(ttasr_ctx* c, int B) {
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemsetAsync(c->st.step, 0, 16, s));
+  HIPCHK(c, hipMemsetAsync(c->st.n_sampled, 0, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.last_tok, 0xff, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.pen_tok, 0xff, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.last_ts, 0xff, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.done, 0, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.n_done, 0, 16, s));
+  HIPCHK(c, hipMemsetAsync(c->st.sum_logprob, 0, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->st.no_speech, 0, B * 4, s));
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* ttasr_version(void) { return "ttasr 0.1 (gfx950, HIP)"; }
+
+const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
+  if (!cfg || !out_ctx) return fail(nullptr, TTASR_E_INVALID, "cfg/out_ctx is NULL");
+  *out_ctx = nullptr;
+  if (cfg->d_model <= 0 || cfg->n_heads <= 0 || cfg->d_model != cfg->n_heads * 64)
+    return fail(nullptr, TTASR_E_INVALID, "head_dim must be 64 (d_model=%d, n_heads=%d)", cfg->d_model, cfg->n_heads);
+  if (cfg->n_mels % 8 || cfg->n_mels <= 0 || cfg->ffn_dim % 64 || cfg->n_audio_ctx < 1 || cfg->vocab < 2 ||
+      cfg->n_text_ctx < 2 || cfg->n_text_ctx > 448 || cfg->enc_layers < 1 || cfg->dec_layers < 1 || cfg->max_batch < 1)
+    return fail(nullptr, TTASR_E_INVALID, "unsupported geometry");
+  if (cfg->compute_type != TTASR_COMPUTE_F32 && cfg->compute_type != TTASR_COMPUTE_BF16)
+    return fail(nullptr, TTASR_E_INVALID, "compute_type must be TTASR_COMPUTE_F32 or TTASR_COMPUTE_BF16");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, TTASR_E_HIP, "no HIP device available (%s); libttasr has no CPU fallback", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, TTASR_E_INVALID, "device %d of %d", device_id, ndev);
+  std::unique_ptr<ttasr_ctx> c(new ttasr_ctx());
+  c->cfg = *cfg; c->device = device_id;
+  c->bf16 = cfg->compute_type == TTASR_COMPUTE_BF16; c->esz = c->bf16 ? 2 : 4;
+  c->T = cfg->n_audio_ctx; c->F = 2 * c->T; c->d = cfg->d_model; c->H = cfg->n_heads; c->ffn = cfg->ffn_dim;
+  c->V = cfg->vocab; c->ldv = (cfg->vocab + 63) / 64 * 64; c->M = cfg->n_mels; c->maxB = cfg->max_batch;
+  c->n_samples = c->F * 160;
+  c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
+  c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
+  ttasr_ctx* p = c.get();
+  auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
+  if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
+    return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
+  int rc = build_weights(p);
+  if (rc) return die(rc);
+  rc = build_workspaces(p);
+  if (rc) return die(rc);
+  *out_ctx = c.release();
+  return TTASR_OK;
+}
+
+void ttasr_destroy(ttasr_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  drop_graphs(c);
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->pinned_i32) hipHostFree(c->pinned_i32);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
+  if (!c) return TTASR_E_INVALID;
+  if (!name || !data || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (std::string(name) == "proj_out.weight") return TTASR_OK;  // tied to embed_tokens
+  auto it = c->slots.find(name);
+  if (it == c->slots.end()) return fail(c, TTASR_E_WEIGHTS, "unknown tensor '%s'", name);
+  Slot& s = it->second;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= dims[i];
+  if (n != s.rows * s.cols) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': %lld elements, expected %lld", name, (long long)n,
+                                        (long long)(s.rows * s.cols));
+  HIPCHK(c, hipSetDevice(c->device));
+  const float* src = data;
+  std::vector<float> tmp;
+  if (s.kind == 2) {  // [out][in][3] -> [out][3][in]: tap-major rows so conv == GEMM over a sliding window
+    if (ndim != 3 || dims[2] != 3) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': expected [out][in][3]", name);
+    const int64_t O = dims[0], I = dims[1];
+    tmp.resize(n);
+    for (int64_t o = 0; o < O; ++o)
+      for (int64_t i = 0; i < I; ++i)
+        for (int k = 0; k < 3; ++k) tmp[(o * 3 + k) * I + i] = data[(o * I + i) * 3 + k];
+    src = tmp.data();
+  } else if (s.scale != 1.0f) {
+    tmp.resize(n);
+    for (int64_t i = 0; i < n; ++i) tmp[i] = data[i] * s.scale;
+    src = tmp.data();
+  }
+  if (s.kind == 1 || s.kind == 3 || !c->bf16) {
+    HIPCHK(c, hipMemcpyAsync(s.dst, src, n * 4, hipMemcpyHostToDevice, c->stream));
+  } else {
+    if ((size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
+    HIPCHK(c, hipMemcpyAsync(c->stage_f32, src, n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // src/tmp are caller/stack owned
+  s.loaded = true;
+  return TTASR_OK;
+}
+
+int ttasr_finalize_weights(ttasr_ctx* c) {
+  if (!c) return TTASR_E_INVALID;
+  for (auto& kv : c->slots)
+    if (!kv.second.loaded) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' was never loaded", kv.first.c_str());
+  c->finalized = true;
+  return TTASR_OK;
+}
+
+int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int64_t* n_samples, int32_t B,
+                  int32_t on_device, float* out_mel) {
+  if (!c) return TTASR_E_INVALID;
+  if (B < 1 || B > c->maxB) return fail(c, TTASR_E_INVALID, "batch %d outside [1, %d]", B, c->maxB);
+  if (!pcm || !n_samples) return fail(c, TTASR_E_INVALID, "pcm / n_samples is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const float* src = pcm;
+  int64_t stride = pcm_stride;
+  std::vector<int64_t> ns(n_samples, n_samples + B);
+  for (int b = 0; b < B; ++b) {
+    if (ns[b] < 0 || ns[b] > pcm_stride) return fail(c, TTASR_E_INVALID, "n_samples[%d]=%lld outside [0, stride]", b, (long long)ns[b]);
+    if (ns[b] > c->n_samples) ns[b] = c->n_samples;  // trim to one window
+  }
+  hipEventRecord(c->ev[0], s);
+  if (!on_device) {
+    for (int b = 0; b < B; ++b)
+      if (ns[b] > 0)
+        HIPCHK(c, hipMemcpyAsync(c->pcm_dev + (int64_t)b * c->n_samples, pcm + b * pcm_stride, ns[b] * 4, hipMemcpyHostToDevice, s));
+    src = c->pcm_dev; stride = c->n_samples;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
+  launch_mel(src, stride, c->nsamp_dev, B, c->M, c->F, c->filters, c->dcos, c->dsin, c->window, c->mel, c->clip_max, s);
+  if (c->bf16) launch_mel_finish<bf16_t>(c->mel, c->clip_max, (bf16_t*)c->mel_t, B, c->M, c->F, s);
+  else launch_mel_finish<float>(c->mel, c->clip_max, (float*)c->mel_t, B, c->M, c->F, s);
+  hipEventRecord(c->ev[1], s);
+  if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);
+  c->B_mel = B;
+  return TTASR_OK;
+}
+
+int ttasr_set_mel(ttasr_ctx* c, const float* mel, int32_t B) {
+  if (!c) return TTASR_E_INVALID;
+  if (B < 1 || B > c->maxB || !mel) return fail(c, TTASR_E_INVALID, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->mel, mel, (size_t)B * c->M * c->F * 4, hipMemcpyHostToDevice, c->stream));
+  if (c->bf16) launch_mel_transpose<bf16_t>(c->mel, (bf16_t*)c->mel_t, B, c->M, c->F, c->stream);
+  else launch_mel_transpose<float>(c->mel, (float*)c->mel_t, B, c->M, c->F, c->stream);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->B_mel = B;
+  return TTASR_OK;
+}
+
+int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
+  TRY(check_ready(c, B));
+  if (c->B_mel < B) return fail(c, TTASR_E_INVALID, "mel for %d clips requested but only %d resident", B, c->B_mel);
+  if (c->bf16) run_encoder<bf16_t>(c, B); else run_encoder<float>(c, B);
+  if (out_enc) {
+    const int64_t n = (int64_t)B * c->T * c->d;
+    if (c->bf16) { launch_uncast<bf16_t>((const bf16_t*)c->enc_out, c->x, n, c->stream);
+                   HIPCHK(c, hipMemcpyAsync(out_enc, c->x, n * 4, hipMemcpyDeviceToHost, c->stream)); }
+    else HIPCHK(c, hipMemcpyAsync(out_enc, c->enc_out, n * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  hipEventElapsedTime(&c->phase_ms[1], c->ev[2], c->ev[3]);
+  hipEventElapsedTime(&c->phase_ms[2], c->ev[3], c->ev[4]);
+  c->B_enc = B;
+  return TTASR_OK;
+}
+
+int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
+  TRY(check_ready(c, B));
+  if (!enc) return fail(c, TTASR_E_INVALID, "enc is NULL");
+  const int64_t n = (int64_t)B * c->T * c->d;
+  if (c->bf16) { HIPCHK(c, hipMemcpyAsync(c->x, enc, n * 4, hipMemcpyHostToDevice, c->stream));
+                 launch_cast<bf16_t>(c->x, (bf16_t*)c->enc_out, n, c->stream); }
+  else HIPCHK(c, hipMemcpyAsync(c->enc_out, enc, n * 4, hipMemcpyHostToDevice, c->stream));
+  if (c->bf16) run_cross_kv<bf16_t>(c, B); else run_cross_kv<float>(c, B);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  c->B_enc = B;
+  return TTASR_OK;
+}
+
+int ttasr_get_cross_kv(ttasr_ctx* c, int32_t layer, int32_t which, int32_t B, float* out) {
+  TRY(check_ready(c, B));
+  if (layer < 0 || layer >= c->cfg.dec_layers || which < 0 || which > 1 || !out || B > c->B_enc)
+    return fail(c, TTASR_E_INVALID, "bad arguments");
+  const int64_t n = (int64_t)B * c->H * c->T * 64;
+  const char* src = (const char*)c->xkv + ((size_t)layer * c->xkv_layer_elems + (size_t)which * c->xkv_which_elems) * c->esz;
+  if (c->bf16) { launch_uncast<bf16_t>((const bf16_t*)src, c->x, n, c->stream);
+                 HIPCHK(c, hipMemcpyAsync(out, c->x, n * 4, hipMemcpyDeviceToHost, c->stream)); }
+  else HIPCHK(c, hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TTASR_OK;
+}
+
+int ttasr_decode_reset(ttasr_ctx* c, int32_t B) {
+  TRY(check_ready(c, B));
+  TRY(reset_search(c, B));
+  c->st.prompt = nullptr; c->st.prompt_len = nullptr;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->B_dec = B;
+  return TTASR_OK;
+}
+
+int ttasr_decode_step(ttasr_ctx* c, const int32_t* tokens, int32_t B, float* logits) {
+  TRY(check_ready(c, B));
+  if (!tokens) return fail(c, TTASR_E_INVALID, "tokens is NULL");
+  if (B != c->B_dec || B > c->B_enc) return fail(c, TTASR_E_INVALID, "call ttasr_encode and ttasr_decode_reset(B) first");
+  for (int b = 0; b < B; ++b)
+    if (tokens[b] < 0 || tokens[b] >= c->V) return fail(c, TTASR_E_INVALID, "token %d outside vocabulary", tokens[b]);
+  HIPCHK(c, hipMemcpyAsync(c->pinned_i32, c->st.step, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->pinned_i32[0] >= c->cfg.n_text_ctx) return fail(c, TTASR_E_INVALID, "decoder context (%d) exhausted", c->cfg.n_text_ctx);
+  HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, tokens, B * 4, hipMemcpyHostToDevice, c->stream));
+  TRY(step_graph(c, B, 1));
+  if (logits) HIPCHK(c, hipMemcpy2DAsync(logits, (size_t)c->V * 4, c->logits, (size_t)c->ldv * 4, (size_t)c->V * 4, B,
+                                         hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  return TTASR_OK;
+}
+
+int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
+                   const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  TRY(check_ready(c, B));
+  if (!prompt || !prompt_len || !out_tokens || !out_len) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
+  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
+  int min_plen = 1 << 30, max_plen = 0;
+  for (int b = 0; b < B; ++b) {
+    if (prompt_len[b] < 1 || prompt_len[b] > max_prompt) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", b, prompt_len[b]);
+    min_plen = std::min(min_plen, prompt_len[b]); max_plen = std::max(max_plen, prompt_len[b]);
+    for (int j = 0; j < prompt_len[b]; ++j)
+      if (prompt[b * max_prompt + j] < 0 || prompt[b * max_prompt + j] >= c->V)
+        return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
+  }
+  RuleParams old = c->rp;
+  TRY(upload_rules(c, o, max_prompt));
+  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_graphs(c);  // rule scalars are baked into the captured launches
+  TRY(reset_search(c, B));
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->plen_dev, prompt_len, B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev, (size_t)max_prompt * 4, 4, B, hipMemcpyDeviceToDevice, s));
+  c->st.prompt = c->prompt_dev; c->st.prompt_len = c->plen_dev;
+  c->B_dec = B;
+  const int interval = std::max(1, o->check_interval);
+  const int last_step = std::min(c->cfg.n_text_ctx, max_plen - 1 + o->max_new_tokens);  // exclusive
+  hipEventRecord(c->ev[5], s);
+  for (int step = 0; step < last_step; ++step) {
+    const bool all_forced = step + 1 < min_plen;
+    const bool need_logits = !all_forced || (o->no_speech >= 0 && step == o->sot_index);
+    TRY(step_graph(c, B, need_logits ? 0 : 2));
+    if (!o->suppress_eot && step + 1 >= min_plen && ((step + 1 - min_plen) % interval == interval - 1)) {
+      HIPCHK(c, hipMemcpyAsync(c->pinned_i32, c->st.n_done, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipStreamSynchronize(s));
+      if (c->pinned_i32[0] >= B) break;
+    }
+  }
+  hipEventRecord(c->ev[6], s);
+  std::vector<int32_t> all((size_t)B * c->rp.max_new);
+  HIPCHK(c, hipMemcpyAsync(out_tokens, c->st.out_tokens, (size_t)B * c->rp.max_new * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out_len, c->st.n_sampled, B * 4, hipMemcpyDeviceToHost, s));
+  if (out_lp) HIPCHK(c, hipMemcpyAsync(out_lp, c->st.sum_logprob, B * 4, hipMemcpyDeviceToHost, s));
+  if (out_ns) HIPCHK(c, hipMemcpyAsync(out_ns, c->st.no_speech, B * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
+  // rows that hit the context limit without EOT keep what they sampled; clamp lengths to max_new
+  for (int b = 0; b < B; ++b) out_len[b] = std::min(out_len[b], c->rp.max_new);
+  return TTASR_OK;
+}
+
+int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int32_t hist_stride, int32_t n,
+                      const ttasr_gen_opts* o, float* out_rows, int32_t* out_choice) {
+  if (!c) return TTASR_E_INVALID;
+  if (n < 1 || n > c->maxB || !rows || !hist || !out_rows) return fail(c, TTASR_E_INVALID, "bad arguments (n <= max_batch)");
+  HIPCHK(c, hipSetDevice(c->device));
+  RuleParams old = c->rp;
+  ttasr_gen_opts oo = *o;
+  oo.max_new_tokens = std::max(1, std::min(oo.max_new_tokens, c->max_new_alloc));
+  TRY(upload_rules(c, &oo, 1));
+  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_graphs(c);
+  TRY(reset_search(c, n));
+  std::vector<int32_t> ns(n), last(n, -1), pen(n, -1), lts(n, -1);
+  for (int r = 0; r < n; ++r) {
+    int k = 0;
+    for (; k < hist_stride && hist[r * hist_stride + k] >= 0; ++k) {
+      int t = hist[r * hist_stride + k];
+      pen[r] = last[r]; last[r] = t;
+      if (t >= o->timestamp_begin) lts[r] = t;
+    }
+    ns[r] = k;
+  }
+  hipStream_t s = c->stream;
+  HIPCHK(c, hipMemcpyAsync(c->st.n_sampled, ns.data(), n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->st.last_tok, last.data(), n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->st.pen_tok, pen.data(), n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->st.last_ts, lts.data(), n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpy2DAsync(c->logits, (size_t)c->ldv * 4, rows, (size_t)c->V * 4, (size_t)c->V * 4, n, hipMemcpyHostToDevice, s));
+  if (!c->rows_out) TRY(dalloc(c, &c->rows_out, (size_t)c->maxB * c->V * 4));
+  DecState st = c->st; st.prompt = nullptr; st.prompt_len = nullptr;
+  RuleParams rp = c->rp; rp.max_new = c->max_new_alloc;  // histories may be longer than opts.max_new_tokens
+  launch_select(c->logits, st, rp, n, c->rows_out, s);
+  HIPCHK(c, hipMemcpyAsync(out_rows, c->rows_out, (size_t)n * c->V * 4, hipMemcpyDeviceToHost, s));
+  if (out_choice) HIPCHK(c, hipMemcpyAsync(out_choice, c->st.cur_tok, n * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return TTASR_OK;
+}
+
+int ttasr_phase_ms(ttasr_ctx* c, float out[4]) {
+  if (!c || !out) return TTASR_E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = c->phase_ms[i];
+  return TTASR_OK;
+}
+
+int ttasr_sync(ttasr_ctx* c) {
+  if (!c) return TTASR_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TTASR_OK;
+}
+
+int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters, float* out_ms, double* out_bytes,
+                       double* out_flops) {
+  TRY(check_ready(c, B));
+  if (!name || iters < 1 || !out_ms) return fail(c, TTASR_E_INVALID, "bad arguments");
+  const std::string k(name);
+  hipStream_t s = c->stream;
+  const double e = (double)c->esz, d = c->d, T_ = c->T, ffn = c->ffn;
+  double bytes = 0, flops = 0;
+  auto once = [&](void) -> int {
+    if (k == "xattn") {
+      const char* Kx = (const char*)c->xkv;
+      if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
+                                                    (bf16_t*)c->datt, B, c->H, c->T, s);
+      else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
+                                           (float*)c->datt, B, c->H, c->T, s);
+      bytes = (double)B * (2.0 * T_ * d + 2.0 * d) * e; flops = (double)B * 4.0 * T_ * d;
+    } else if (k == "enc_gemm_fc1") {
+      GemmArgs g; g.A = c->h; g.W = c->enc[0].w1; g.M = B * c->T; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
+      g.epi.ldc = c->ffn; g.epi.bias = c->enc[0].b1; g.epi.act = 1; g.epi.out_t = c->mid;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = ((double)B * T_ * (d + ffn) + ffn * d) * e; flops = 2.0 * B * T_ * d * ffn;
+    } else if (k == "enc_attn") {
+      if (c->bf16) {
+        if (!c->force_basic && getenv("TTASR_FLASH")) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
+        else launch_enc_attn_simple<bf16_t>((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
+      } else launch_enc_attn_simple<float>((const float*)c->qkv, (float*)c->att, B, c->T, c->H, s);
+      bytes = (double)B * T_ * 4.0 * d * e; flops = 4.0 * B * T_ * T_ * d;
+    } else if (k == "dec_gemm_fc1") {
+      GemmArgs g; g.A = c->dh; g.W = c->dec[0].w1; g.M = B; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
+      g.epi.ldc = c->ffn; g.epi.bias = c->dec[0].b1; g.epi.act = 1; g.epi.out_t = c->dmid;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = (ffn * d + (double)B * (d + ffn)) * e; flops = 2.0 * B * d * ffn;
+    } else if (k == "logits_gemm") {
+      GemmArgs g; g.A = c->dh; g.W = c->emb; g.M = B; g.N = c->V; g.K = c->d; g.lda = c->d; g.ldw = c->d;
+      g.epi.ldc = c->ldv; g.epi.out_f32 = c->logits;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = (double)c->V * d * e + (double)B * c->V * 4.0; flops = 2.0 * B * d * c->V;
+    } else {
+      return fail(c, TTASR_E_INVALID, "unknown kernel '%s'", name);
+    }
+    return 0;
+  };
+  TRY(once());
+  HIPCHK(c, hipStreamSynchronize(s));
+  hipEventRecord(c->ev[7], s);
+  for (int i = 0; i < iters; ++i) TRY(once());
+  hipEventRecord(c->ev[0], s);
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, c->ev[7], c->ev[0]);
+  *out_ms = ms / iters;
+  if (out_bytes) *out_bytes = bytes;
+  if (out_flops) *out_flops = flops;
+  return TTASR_OK;
+}
+
+}  // extern "C"

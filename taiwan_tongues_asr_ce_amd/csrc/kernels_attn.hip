@@ -1,0 +1,313 @@
+// Attention kernels (head_dim = 64 everywhere in Whisper).
+//   enc_attn_simple<T>     encoder self-attention, f32 VALU flash loop (parity mode / fallback)
+//   self_attn_decode<T>    one new token per row against the paged self-KV cache (append + attend)
+//   cross_attn_decode<T>   one query per (row, head) against the 1500-frame cross-KV: the HBM-dominant
+//                          kernel of the whole decode
+// Replaces CTranslate2's MultiHeadAttention layer (un-vendored; arithmetic per HF modeling_whisper.py
+// :215-238, 241-356): q arrives pre-scaled by 1/8 (folded into the weights), softmax in f32.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// encoder attention, simple form.  Block = 4 waves = 16 queries of one (b, h); K/V tiles of 64 keys
+// staged in LDS as f32.  QK: lane = key.  PV: lane = output dim.  Online softmax per query.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void enc_attn_simple_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn,
+                                                               int H) {
+  constexpr int QB = 16, KB = 64, HD = 64;
+  __shared__ float Ks[KB][HD + 1];
+  __shared__ float Vs[KB][HD];
+  __shared__ float Qs[QB][HD];
+  __shared__ float Ps[4][KB];
+  const int d = H * HD, ld = 3 * d;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* base = qkv + (int64_t)b * Tn * ld + h * HD;
+  for (int i = tid; i < QB * HD; i += 256) {
+    int qi = i >> 6, c = i & 63;
+    Qs[qi][c] = (q0 + qi < Tn) ? to_f<T>(base[(int64_t)(q0 + qi) * ld + c]) : 0.f;
+  }
+  float m_run[4], l_run[4], o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { m_run[j] = -1e30f; l_run[j] = 0.f; o[j] = 0.f; }
+  for (int k0 = 0; k0 < Tn; k0 += KB) {
+    __syncthreads();
+    for (int i = tid; i < KB * HD; i += 256) {
+      int kr = i >> 6, c = i & 63;
+      bool ok = k0 + kr < Tn;
+      Ks[kr][c] = ok ? to_f<T>(base[(int64_t)(k0 + kr) * ld + d + c]) : 0.f;
+      Vs[kr][c] = ok ? to_f<T>(base[(int64_t)(k0 + kr) * ld + 2 * d + c]) : 0.f;
+    }
+    __syncthreads();
+    const bool kvalid = k0 + lane < Tn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qi = wave * 4 + j;
+      float s = 0.f;
+#pragma unroll 16
+      for (int c = 0; c < HD; ++c) s = fmaf(Qs[qi][c], Ks[lane][c], s);
+      s = kvalid ? s : -1e30f;
+      float mt = wave_max(s);
+      float mn = fmaxf(m_run[j], mt);
+      float p = kvalid ? __expf(s - mn) : 0.f;
+      float alpha = __expf(m_run[j] - mn);
+      float ps = wave_sum(p);
+      l_run[j] = l_run[j] * alpha + ps;
+      m_run[j] = mn;
+      Ps[wave][lane] = p;
+      __builtin_amdgcn_wave_barrier();
+      float acc = 0.f;
+#pragma unroll 16
+      for (int kk = 0; kk < KB; ++kk) acc = fmaf(Ps[wave][kk], Vs[kk][lane], acc);
+      o[j] = o[j] * alpha + acc;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int qi = q0 + wave * 4 + j;
+    if (qi < Tn) out[((int64_t)b * Tn + qi) * d + h * HD + lane] = from_f<T>(o[j] / l_run[j]);
+  }
+}
+template <typename T>
+void launch_enc_attn_simple(const T* qkv, T* out, int B, int Tn, int H, hipStream_t s) {
+  dim3 grid((Tn + 15) / 16, H, B);
+  hipLaunchKernelGGL(enc_attn_simple_kernel<T>, grid, dim3(256), 0, s, qkv, out, Tn, H);
+}
+template void launch_enc_attn_simple<float>(const float*, float*, int, int, int, hipStream_t);
+template void launch_enc_attn_simple<bf16_t>(const bf16_t*, bf16_t*, int, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// helpers: one 16-byte chunk of a K/V row per lane.  VEC elements, LPR lanes per 64-element row.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct RowVec;
+template <> struct RowVec<float> {
+  static constexpr int VEC = 4;
+  __device__ static void load(const float* p, float (&v)[4]) {
+    float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+template <> struct RowVec<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static void load(const bf16_t* p, float (&v)[8]) {
+    uint4 t = *(const uint4*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// decoder self-attention with paged KV cache.
+// Pool layout per layer: [page][2 (K,V)][H][PAGE=16 tokens][64]; page_table[b][i] = page of tokens
+// 16i..16i+15 of row b (beam search re-indexes pages instead of copying the cache).
+// One wave per (b, h): appends this step's k,v at position pos = *step, then attends over pos+1 keys.
+// ------------------------------------------------------------------------------------------------
+constexpr int PAGE = 16;
+
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
+                                                              const int32_t* __restrict__ page_table, int pages_per_seq,
+                                                              const int32_t* __restrict__ step, T* __restrict__ out, int H) {
+  constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
+  __shared__ float sc[448 + 64];
+  const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+  const int d = H * 64, pos = *step;
+  const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
+  const int sub = lane % LPR, rin = lane / LPR;
+  float q[VEC], kn[VEC], vn[VEC];
+  RowVec<T>::load(qp + sub * VEC, q);
+  RowVec<T>::load(qp + d + sub * VEC, kn);
+  RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
+  // append (lanes of row-slot 0 write the new k and v)
+  {
+    int page = page_table[b * pages_per_seq + pos / PAGE];
+    T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
+    T* vdst = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (pos % PAGE)) * 64;
+    if (rin == 0) {
+      *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
+      *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
+    }
+  }
+  // scores for cached keys 0..pos-1 (the new key is handled from registers)
+  float mloc = -1e30f;
+  for (int t0 = 0; t0 < pos; t0 += RPI) {
+    int t = t0 + rin;
+    float s = 0.f;
+    if (t < pos) {
+      int page = page_table[b * pages_per_seq + t / PAGE];
+      const T* kp = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (t % PAGE)) * 64 + sub * VEC;
+      float kv[VEC];
+      RowVec<T>::load(kp, kv);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[j], s);
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    if (t < pos) {
+      if (sub == 0) sc[t] = s;
+      mloc = fmaxf(mloc, s);
+    }
+  }
+  float snew = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) snew = fmaf(q[j], kn[j], snew);
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) snew += __shfl_xor(snew, o);
+  const float mx = fmaxf(wave_max(mloc), snew);
+  __syncthreads();
+  float lsum = 0.f;
+  for (int t = lane; t < pos; t += 64) {
+    float p = __expf(sc[t] - mx);
+    sc[t] = p;
+    lsum += p;
+  }
+  const float pnew = __expf(snew - mx);
+  const float denom = wave_sum(lsum) + pnew;
+  __syncthreads();
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = (rin == 0) ? pnew * vn[j] : 0.f;
+  for (int t0 = 0; t0 < pos; t0 += RPI) {
+    int t = t0 + rin;
+    if (t < pos) {
+      int page = page_table[b * pages_per_seq + t / PAGE];
+      const T* vp = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (t % PAGE)) * 64 + sub * VEC;
+      float vv[VEC];
+      RowVec<T>::load(vp, vv);
+      float p = sc[t];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vv[j], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+  }
+  if (rin == 0) {
+    T* op = out + (int64_t)b * d + h * 64 + sub * VEC;
+    const float inv = 1.0f / denom;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) op[j] = from_f<T>(acc[j] * inv);
+  }
+}
+template <typename T>
+void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
+                             const int32_t* step, T* out, int B, int H, hipStream_t s) {
+  hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(64), 0, s, qkv, kv_pool + pool_layer_off, page_table,
+                     pages_per_seq, step, out, H);
+}
+template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, const int32_t*, float*, int,
+                                             int, hipStream_t);
+template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, const int32_t*, bf16_t*,
+                                              int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// decoder cross-attention.  K, V: [B][H][Tk][64] (head-major, written by the cross-KV GEMM epilogue), so
+// the 2*Tk*128 B (bf16) a workgroup needs are two contiguous streams read with 16 B per lane, 1 KiB per
+// wave-instruction.  One workgroup (4 waves) per (b, h):
+//   phase A  stream K: lane owns one 16-B chunk of a frame, LPR lanes reduce by shuffles -> score to LDS
+//   softmax  exact two-pass in f32 over the Tk scores held in LDS
+//   phase B  stream V: acc[j] += p[t] * v[t][j]; reduce over the row-slots of the wave, then over waves
+// Algorithmic bytes per launch: B*H*2*Tk*64*sizeof(T) (+ q, out): 245.8 MB per clip-step-layer... see DESIGN.md.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
+                                                                const T* __restrict__ V, T* __restrict__ out, int H, int Tk) {
+  constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
+  constexpr int UNROLL = 4;
+  extern __shared__ float sc[];  // [Tk] scores, then [4][64] partial outputs, [8] reductions
+  const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = H * 64;
+  const int sub = lane % LPR, rin = lane / LPR;
+  float* part = sc + Tk;        // [4][64]
+  float* red = part + 4 * 64;   // [8]
+  float qv[VEC];
+  RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  const T* Kp = K + ((int64_t)b * H + h) * Tk * 64;
+  const T* Vp = V + ((int64_t)b * H + h) * Tk * 64;
+  float mloc = -1e30f;
+  // rows handled by this wave: t = (it*4 + wave)*RPI + rin
+  const int n_it = (Tk + 4 * RPI - 1) / (4 * RPI);
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    float kv[UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      if (t < Tk) RowVec<T>::load(Kp + (int64_t)t * 64 + sub * VEC, kv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      float s = 0.f;
+      if (t < Tk) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kv[u][j], s);
+      }
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+      if (t < Tk) {
+        if (sub == 0) sc[t] = s;
+        mloc = fmaxf(mloc, s);
+      }
+    }
+  }
+  mloc = wave_max(mloc);
+  if (lane == 0) red[wave] = mloc;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float lsum = 0.f;
+  for (int t = tid; t < Tk; t += 256) {
+    float p = __expf(sc[t] - mx);
+    sc[t] = p;
+    lsum += p;
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[4 + wave] = lsum;
+  __syncthreads();
+  const float denom = (red[4] + red[5]) + (red[6] + red[7]);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    float vv[UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      if (t < Tk) RowVec<T>::load(Vp + (int64_t)t * 64 + sub * VEC, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      if (t < Tk) {
+        float p = sc[t];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vv[u][j], acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+  }
+  if (rin == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[wave * 64 + sub * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
+  }
+}
+template <typename T>
+void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, hipStream_t s) {
+  size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
+  hipLaunchKernelGGL(cross_attn_decode_kernel<T>, dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk);
+}
+template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
+template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, hipStream_t);

@@ -1,0 +1,172 @@
+// Decoder glue kernels: token+position embedding, and the fused logits-processor / greedy-selection
+// kernel.  The selection kernel restates CTranslate2's Whisper logits processors + greedy search
+// (un-vendored) == HF generation/logits_process.py:1816 (begin-suppress), :1869 (suppress),
+// :2000-2047 (timestamp rules), generation_whisper.py:1774-1812 (stack order); tie-breaking = first
+// maximum, as torch.argmax.  All search state lives in device memory so a whole decode step can be
+// replayed as a hipGraph with no host round trip.
+#include "common.hpp"
+
+template <typename T>
+__global__ void embed_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ step, const T* __restrict__ emb,
+                             const T* __restrict__ pos, float* __restrict__ x, int d) {
+  const int b = blockIdx.x, p = *step;
+  const T* e = emb + (int64_t)tok[b] * d;
+  const T* pe = pos + (int64_t)p * d;
+  for (int i = threadIdx.x; i < d; i += blockDim.x) x[(int64_t)b * d + i] = to_f<T>(e[i]) + to_f<T>(pe[i]);
+}
+template <typename T>
+void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, s, tok, step, emb, pos, x, d);
+}
+template void launch_embed<float>(const int32_t*, const int32_t*, const float*, const float*, float*, int, int, hipStream_t);
+template void launch_embed<bf16_t>(const int32_t*, const int32_t*, const bf16_t*, const bf16_t*, float*, int, int, hipStream_t);
+
+__global__ void advance_kernel(int32_t* step) { *step += 1; }
+void launch_advance(int32_t* step, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step); }
+
+// ------------------------------------------------------------------------------------------------
+struct RowRule {  // per-row view of the rules at this step
+  int n, last_is_ts, pen_is_ts, ts_floor;  // ts_floor: timestamps < ts_floor are masked (or 0)
+};
+
+__device__ __forceinline__ bool masked(int i, const RowRule& r, const RuleParams& p, const uint8_t* __restrict__ mask) {
+  uint8_t mk = mask[i];
+  if (mk & 1) return true;
+  if (r.n == 0 && (mk & 2)) return true;
+  if (p.suppress_eot && i == p.eot) return true;
+  if (p.timestamps) {
+    const int tb = p.timestamp_begin;
+    if (i == p.no_timestamps) return true;
+    if (r.last_is_ts) {
+      if (r.pen_is_ts) { if (i >= tb) return true; }
+      else if (i < p.eot) return true;
+    }
+    if (i >= tb && i < r.ts_floor) return true;
+    if (r.n == 0) {
+      if (i < tb) return true;
+      if (p.max_initial >= 0 && i > tb + p.max_initial) return true;
+    }
+  }
+  return false;
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax am_merge(ArgMax a, ArgMax b) {
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgMax am_wave(ArgMax a) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax b{__shfl_xor(a.v, o), __shfl_xor(a.i, o)};
+    a = am_merge(a, b);
+  }
+  return a;
+}
+
+// One workgroup (1024 threads) per row.  Pass 1: masked max/argmax of the text and timestamp ranges.
+// Pass 2: sum of exp over both ranges (f32).  Then the "timestamp mass > best text token" rule, the
+// choice, its log-probability, and the state update.  Reads the V-float row twice from L2.
+__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ logits, DecState st, RuleParams p,
+                                                      float* __restrict__ out_rows) {
+  __shared__ ArgMax s_am[2][16];
+  __shared__ float s_sum[3][16];
+  __shared__ float s_b[8];
+  __shared__ int s_i[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * p.ldv;
+  const int step = *st.step;
+  const int plen = st.prompt_len ? st.prompt_len[b] : 1;
+  const bool forced = st.prompt && (step + 1 < plen);
+  const bool want_ns = p.no_speech >= 0 && step == p.sot_index && st.no_speech;
+  if (forced && !want_ns && !out_rows) {
+    if (tid == 0) st.cur_tok[b] = st.prompt[b * p.max_prompt + step + 1];
+    return;
+  }
+  RowRule r;
+  r.n = st.n_sampled[b];
+  const int last = st.last_tok[b], pen = st.pen_tok[b], lts = st.last_ts[b];
+  const int tb = p.timestamp_begin;
+  r.last_is_ts = (r.n >= 1 && last >= tb);
+  r.pen_is_ts = (r.n < 2 || pen >= tb);
+  r.ts_floor = (lts >= 0) ? ((r.last_is_ts && !r.pen_is_ts) ? lts : lts + 1) : 0;
+
+  ArgMax a_txt{-INFINITY, 0x7fffffff}, a_ts{-INFINITY, 0x7fffffff};
+  float raw_max = -INFINITY;
+  for (int i = tid; i < p.V; i += 1024) {
+    float v = row[i];
+    raw_max = fmaxf(raw_max, v);
+    bool mk = masked(i, r, p, st.mask);
+    if (out_rows) out_rows[(int64_t)b * p.V + i] = mk ? -INFINITY : v;
+    if (!mk) {
+      ArgMax c{v, i};
+      if (p.timestamps && i >= tb) a_ts = am_merge(a_ts, c); else a_txt = am_merge(a_txt, c);
+    }
+  }
+  a_txt = am_wave(a_txt);
+  a_ts = am_wave(a_ts);
+  raw_max = wave_max(raw_max);
+  if (lane == 0) { s_am[0][wave] = a_txt; s_am[1][wave] = a_ts; s_sum[2][wave] = raw_max; }
+  __syncthreads();
+  if (wave == 0) {
+    ArgMax x = lane < 16 ? s_am[0][lane] : ArgMax{-INFINITY, 0x7fffffff};
+    ArgMax y = lane < 16 ? s_am[1][lane] : ArgMax{-INFINITY, 0x7fffffff};
+    float z = lane < 16 ? s_sum[2][lane] : -INFINITY;
+    x = am_wave(x); y = am_wave(y); z = wave_max(z);
+    if (lane == 0) { s_b[0] = x.v; s_i[0] = x.i; s_b[1] = y.v; s_i[1] = y.i; s_b[2] = z; }
+  }
+  __syncthreads();
+  const float mx_txt = s_b[0], mx_ts = s_b[1], mx_raw = s_b[2];
+  const int i_txt = s_i[0], i_ts = s_i[1];
+  const float mx_all = fmaxf(mx_txt, mx_ts);
+  float sum_txt = 0.f, sum_ts = 0.f, sum_raw = 0.f;
+  for (int i = tid; i < p.V; i += 1024) {
+    float v = row[i];
+    if (want_ns) sum_raw += __expf(v - mx_raw);
+    if (!masked(i, r, p, st.mask)) {
+      float e = __expf(v - mx_all);
+      if (p.timestamps && i >= tb) sum_ts += e; else sum_txt += e;
+    }
+  }
+  sum_txt = wave_sum(sum_txt); sum_ts = wave_sum(sum_ts); sum_raw = wave_sum(sum_raw);
+  __syncthreads();
+  if (lane == 0) { s_sum[0][wave] = sum_txt; s_sum[1][wave] = sum_ts; s_sum[2][wave] = sum_raw; }
+  __syncthreads();
+  if (tid == 0) {
+    s_i[2] = 0;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < 16; ++w) { t0 += s_sum[0][w]; t1 += s_sum[1][w]; t2 += s_sum[2][w]; }
+    if (want_ns) st.no_speech[b] = __expf(row[p.no_speech] - mx_raw) / t2;
+    if (forced) {
+      st.cur_tok[b] = st.prompt[b * p.max_prompt + step + 1];
+    } else if (st.done[b]) {
+      st.cur_tok[b] = p.eot;
+    } else {
+      // logsumexp(timestamps) > max(text)  <=>  log(t1) + mx_all > mx_txt   (common -lse cancels)
+      bool force_ts = p.timestamps && t1 > 0.f && (__logf(t1) + mx_all > mx_txt);
+      s_i[2] = force_ts;
+      int choice; float cv, lse;
+      if (force_ts) { choice = i_ts; cv = mx_ts; lse = __logf(t1) + mx_all; }
+      else {
+        bool pick_ts = mx_ts > mx_txt;  // ties go to the lower index, i.e. text
+        choice = pick_ts ? i_ts : i_txt; cv = pick_ts ? mx_ts : mx_txt; lse = __logf(t0 + t1) + mx_all;
+      }
+      st.cur_tok[b] = choice;
+      st.sum_logprob[b] += cv - lse;
+      if (r.n < p.max_new) st.out_tokens[b * p.max_new + r.n] = choice;
+      st.n_sampled[b] = r.n + 1;
+      st.pen_tok[b] = last;
+      st.last_tok[b] = choice;
+      if (choice >= tb && p.timestamps) st.last_ts[b] = choice;
+      if (choice == p.eot || r.n + 1 >= p.max_new) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
+    }
+  }
+  if (out_rows) {  // known-answer hook: the forced-timestamp branch also masks the text range
+    __syncthreads();
+    if (s_i[2])
+      for (int i = tid; i < tb; i += 1024) out_rows[(int64_t)b * p.V + i] = -INFINITY;
+  }
+}
+
+void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows, hipStream_t s) {
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, s, logits, st, rp, out_rows);
+}

@@ -1,0 +1,228 @@
+// GEMM kernels: C[M][N] = A[M][K] * W[N][K]^T with fused epilogues (bias / GELU / positions / residual /
+// head-split scatter).  Replaces CTranslate2's Dense + Conv1D layers on the Whisper hot path
+// (SURVEY.md section 2.1).  Both operands are K-contiguous ("B^T input"), which is exactly PyTorch's
+// Linear weight layout, so MFMA A and B fragments are plain 16-byte row reads.
+//
+//   gemm_basic<T>   64x64x32 tile, register-staged LDS, any M/N/K (K % 8 == 0).  T = float uses the
+//                   exact-f32 MFMA v_mfma_f32_16x16x4_f32 (parity mode), T = bf16 v_mfma_f32_16x16x32_bf16.
+//   gemm_bf16_fast  128x128x64 tile, global_load_lds (16 B) double-buffered staging, XOR-swizzled LDS
+//                   image (swizzle applied on the SOURCE address, guide rule 21), XCD-aware tile order.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// epilogue
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void epi_store(const GemmEpi& e, int64_t zoff, int m, int n, float v) {
+  if (e.bias) v += e.bias[n];
+  if (e.act == 1) v = gelu_erf(v);
+  if (e.rowtab) v += e.rowtab[(int64_t)(m % e.rowmod) * e.ldc + n];
+  int64_t idx = zoff + (int64_t)m * e.ldc + n;
+  if (e.residual) v += e.residual[idx];
+  if (e.out_f32) e.out_f32[idx] = v;
+  if (e.out_t) {
+    if (e.headsplit) {
+      int which = n / e.hs_d, nn = n - which * e.hs_d;
+      int h = nn >> 6, j = nn & 63;
+      int b = m / e.hs_T, t = m - b * e.hs_T;
+      idx = (int64_t)which * e.hs_which + (((int64_t)b * e.hs_H + h) * e.hs_T + t) * 64 + j;
+    }
+    ((T*)e.out_t)[idx] = from_f<T>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_basic
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct BasicCfg;
+template <> struct BasicCfg<float> { static constexpr int VEC = 4, PAD = 4; };
+template <> struct BasicCfg<bf16_t> { static constexpr int VEC = 8, PAD = 8; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_basic_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  constexpr int VEC = BasicCfg<T>::VEC, LDK = BK + BasicCfg<T>::PAD, VPR = BK / VEC;
+  __shared__ __attribute__((aligned(16))) T As[BM * LDK];
+  __shared__ __attribute__((aligned(16))) T Ws[BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const T* A = (const T*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
+  const T* W = (const T*)g.W;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    for (int v = tid; v < BM * VPR; v += 256) {
+      int r = v / VPR, c = v - r * VPR;
+      int k = k0 + c * VEC;
+      uint4 va = make_uint4(0, 0, 0, 0), vw = make_uint4(0, 0, 0, 0);
+      if (k < g.K) {
+        if (m0 + r < g.M) va = *(const uint4*)(A + (int64_t)(m0 + r) * g.lda + k);
+        if (n0 + r < g.N) vw = *(const uint4*)(W + (int64_t)(n0 + r) * g.ldw + k);
+      }
+      *(uint4*)(As + r * LDK + c * VEC) = va;
+      *(uint4*)(Ws + r * LDK + c * VEC) = vw;
+    }
+    __syncthreads();
+    if constexpr (sizeof(T) == 2) {
+      s16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *(const s16x8*)(As + (wm * 32 + i * 16 + (lane & 15)) * LDK + 8 * (lane >> 4));
+        b[i] = *(const s16x8*)(Ws + (wn * 32 + i * 16 + (lane & 15)) * LDK + 8 * (lane >> 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        float a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[i] = ((const float*)As)[(wm * 32 + i * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
+          b[i] = ((const float*)Ws)[(wn * 32 + i * 16 + (lane & 15)) * LDK + kk * 4 + (lane >> 4)];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t zoff = (int64_t)blockIdx.z * g.epi.batch_stride_c;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+        int n = n0 + wn * 32 + j * 16 + (lane & 15);
+        if (m < g.M && n < g.N) epi_store<T>(g.epi, zoff, m, n, acc[i][j][r]);
+      }
+}
+
+template <typename T>
+void launch_gemm_basic(const GemmArgs& g, hipStream_t s) {
+  dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, g.batch);
+  hipLaunchKernelGGL(gemm_basic_kernel<T>, grid, dim3(256), 0, s, g);
+}
+template void launch_gemm_basic<float>(const GemmArgs&, hipStream_t);
+template void launch_gemm_basic<bf16_t>(const GemmArgs&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// gemm_bf16_fast: 128x128x64, glds double buffer
+// ------------------------------------------------------------------------------------------------
+// LDS image per operand tile: [128 rows][8 chunks of 16 B]; chunk slot s of row r holds global chunk
+// s ^ (r & 7) (source-side swizzle), so a 16-lane ds_read_b128 group (16 rows, one k-chunk) covers all 64
+// banks exactly once.
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buf][A 16K | W 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous range of tiles; n runs fastest so neighbours share the A panel in that XCD's L2.
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* A = (const bf16_t*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
+  const bf16_t* W = (const bf16_t*)g.W;
+
+  // staging assignment: wave w issues 4 A pieces + 4 W pieces per k-tile; piece p covers rows 8p..8p+7
+  const int srow = lane >> 3, sslot = lane & 7;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int row = (wave * 4 + p) * 8 + srow;
+    int chunk = sslot ^ (row & 7);
+    int am = min(m0 + row, g.M - 1);  // clamp: rows >= M are loaded but never stored
+    a_src[p] = A + (int64_t)am * g.lda + chunk * 8;
+    w_src[p] = W + (int64_t)(n0 + row) * g.ldw + chunk * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+    char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      glds16(a_src[p] + k0, base + (wave * 4 + p) * 1024);
+      glds16(w_src[p] + k0, base + TILE_BYTES + (wave * 4 + p) * 1024);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / BK;
+  stage(0, 0);
+  __syncthreads();  // drains vmcnt(0): tile 0 landed
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
+    const char* As = smem + cur * 2 * TILE_BYTES;
+    const char* Ws = As + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ra = wm * 64 + i * 16 + fr;
+        a[i] = *(const s16x8*)(As + ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
+        int rb = wn * 64 + i * 16 + fr;
+        b[i] = *(const s16x8*)(Ws + rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next tile landed (vmcnt(0)) and everyone finished reading `cur`
+  }
+
+  const int64_t zoff = (int64_t)blockIdx.z * g.epi.batch_stride_c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        int m = m0 + wm * 64 + i * 16 + fq * 4 + rr;
+        int n = n0 + wn * 64 + j * 16 + fr;
+        if (m < g.M) epi_store<bf16_t>(g.epi, zoff, m, n, acc[i][j][rr]);
+      }
+}
+
+bool gemm_bf16_fast_ok(const GemmArgs& g) {
+  return g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.M >= 1 &&
+         ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0;
+}
+
+void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s) {
+  int tiles_m = (g.M + 127) / 128, tiles_n = g.N / 128;
+  dim3 grid(tiles_m * tiles_n, 1, g.batch);
+  hipLaunchKernelGGL(gemm_bf16_fast_kernel, grid, dim3(256), 65536, s, g, tiles_m, tiles_n);
+}

@@ -1,0 +1,208 @@
+// Log-mel front end, LayerNorm and small utility kernels.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// a5: log-mel.  Restates FeatureExtractor.__call__ of faster-whisper == HF feature_extraction_whisper.py
+// :135-168: reflect-pad 200, Hann-400 frames at hop 160, |DFT|^2 (201 bins), slaney mel matmul,
+// log10(max(., 1e-10)); the per-clip "max - 8" clamp and (x+4)/4 need the clip maximum, so this kernel
+// writes raw log10 values and an ordered-uint atomic max per clip, and mel_finish applies the rest.
+// One workgroup = 8 consecutive frames of one clip: the 1520 samples they span are read once, coalesced,
+// into LDS; thread k owns DFT bin k for all 8 frames (twiddles from a 400-entry LDS table, index k*n mod
+// 400); then thread m owns mel bin m.  HBM traffic = PCM once + output once.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+constexpr int MEL_F = 8;             // frames per workgroup
+constexpr int MEL_SPAN = 160 * (MEL_F - 1) + 400;  // 1520
+
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ pcm, int64_t pcm_stride,
+                                                  const int64_t* __restrict__ n_samples, int n_mels, int n_frames,
+                                                  const float* __restrict__ filters, const float* __restrict__ dcos,
+                                                  const float* __restrict__ dsin, const float* __restrict__ window,
+                                                  float* __restrict__ logmel, unsigned* __restrict__ clip_max) {
+  __shared__ float xs[MEL_SPAN];
+  __shared__ float tc[400], tsn[400], win[400];
+  __shared__ float pw[MEL_F][208];
+  __shared__ float red[4];
+  const int b = blockIdx.y, f0 = blockIdx.x * MEL_F, tid = threadIdx.x;
+  const int64_t n_valid = min((int64_t)n_frames * 160, n_samples[b]);
+  const int64_t total = (int64_t)n_frames * 160;  // window length the clip is padded / trimmed to
+  const float* x = pcm + (int64_t)b * pcm_stride;
+  for (int i = tid; i < 400; i += 256) { tc[i] = dcos[i]; tsn[i] = dsin[i]; win[i] = window[i]; }
+  // sample index of xs[i] in the padded clip: s = f0*160 - 200 + i, reflected at both ends
+  for (int i = tid; i < MEL_SPAN; i += 256) {
+    int64_t sidx = (int64_t)f0 * 160 - 200 + i;
+    if (sidx < 0) sidx = -sidx;
+    if (sidx >= total) sidx = 2 * (total - 1) - sidx;
+    xs[i] = (sidx >= 0 && sidx < n_valid) ? x[sidx] : 0.0f;
+  }
+  __syncthreads();
+  if (tid < 201) {
+    float re[MEL_F], im[MEL_F];
+#pragma unroll
+    for (int f = 0; f < MEL_F; ++f) { re[f] = 0.f; im[f] = 0.f; }
+    int idx = 0;
+    for (int n = 0; n < 400; ++n) {
+      float c = tc[idx], s = tsn[idx], w = win[n];
+#pragma unroll
+      for (int f = 0; f < MEL_F; ++f) {
+        float v = xs[f * 160 + n] * w;
+        re[f] = fmaf(v, c, re[f]);
+        im[f] = fmaf(v, s, im[f]);
+      }
+      idx += tid;
+      if (idx >= 400) idx -= 400;
+    }
+#pragma unroll
+    for (int f = 0; f < MEL_F; ++f) pw[f][tid] = re[f] * re[f] + im[f] * im[f];
+  }
+  __syncthreads();
+  float lmax = -1e30f;
+  for (int o = tid; o < n_mels * MEL_F; o += 256) {
+    int m = o % n_mels, f = o / n_mels;
+    if (f0 + f < n_frames) {
+      float acc = 0.f;
+      for (int k = 0; k < 201; ++k) acc = fmaf(pw[f][k], filters[k * n_mels + m], acc);
+      float l = log10f(fmaxf(acc, 1e-10f));
+      logmel[((int64_t)b * n_mels + m) * n_frames + f0 + f] = l;
+      lmax = fmaxf(lmax, l);
+    }
+  }
+  lmax = wave_max(lmax);
+  if ((tid & 63) == 0) red[tid >> 6] = lmax;
+  __syncthreads();
+  if (tid == 0) atomicMax(&clip_max[b], f2ord(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
+                const float* filters, const float* dft_cos, const float* dft_sin, const float* window, float* logmel,
+                unsigned* clip_max, hipStream_t s) {
+  hipMemsetAsync(clip_max, 0, sizeof(unsigned) * B, s);
+  dim3 grid((n_frames + MEL_F - 1) / MEL_F, B);
+  hipLaunchKernelGGL(mel_kernel, grid, dim3(256), 0, s, pcm, pcm_stride, n_samples_dev, n_mels, n_frames, filters,
+                     dft_cos, dft_sin, window, logmel, clip_max);
+}
+
+// normalise in place ([B][M][F] f32, the API-visible layout) and write the encoder's input image:
+// time-major [B][F+2][M] in T with a zero row before and after each clip (conv padding, see engine).
+template <typename T>
+__global__ __launch_bounds__(256) void mel_finish_kernel(float* __restrict__ logmel, const unsigned* __restrict__ clip_max,
+                                                         T* __restrict__ mel_t, int n_mels, int n_frames, int normalise) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, f0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float floor_v = normalise ? ord2f(clip_max[b]) - 8.0f : 0.f;
+  for (int r = ty; r < 32; r += 8) {
+    int m = m0 + r, f = f0 + tx;
+    if (m < n_mels && f < n_frames) {
+      int64_t i = ((int64_t)b * n_mels + m) * n_frames + f;
+      float v = logmel[i];
+      if (normalise) {
+        v = (fmaxf(v, floor_v) + 4.0f) * 0.25f;
+        logmel[i] = v;
+      }
+      tile[r][tx] = v;
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int f = f0 + r, m = m0 + tx;
+    if (m < n_mels && f < n_frames) mel_t[((int64_t)b * (n_frames + 2) + f + 1) * n_mels + m] = from_f<T>(tile[tx][r]);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {  // zero the two padding rows of this clip
+    for (int i = threadIdx.x; i < n_mels; i += 256) {
+      mel_t[(int64_t)b * (n_frames + 2) * n_mels + i] = from_f<T>(0.f);
+      mel_t[((int64_t)b * (n_frames + 2) + n_frames + 1) * n_mels + i] = from_f<T>(0.f);
+    }
+  }
+}
+
+template <typename T>
+void launch_mel_finish(float* logmel, const unsigned* clip_max, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s) {
+  dim3 grid((n_frames + 31) / 32, (n_mels + 31) / 32, B);
+  hipLaunchKernelGGL(mel_finish_kernel<T>, grid, dim3(256), 0, s, logmel, clip_max, mel_t, n_mels, n_frames, 1);
+}
+template <typename T>
+void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s) {
+  dim3 grid((n_frames + 31) / 32, (n_mels + 31) / 32, B);
+  hipLaunchKernelGGL(mel_finish_kernel<T>, grid, dim3(256), 0, s, (float*)mel, (const unsigned*)nullptr, mel_t, n_mels,
+                     n_frames, 0);
+}
+template void launch_mel_finish<float>(float*, const unsigned*, float*, int, int, int, hipStream_t);
+template void launch_mel_finish<bf16_t>(float*, const unsigned*, bf16_t*, int, int, int, hipStream_t);
+template void launch_mel_transpose<float>(const float*, float*, int, int, int, hipStream_t);
+template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-5), f32 residual stream in -> T out.  One wave per row, float4 loads, two-pass
+// variance (mean first) exactly as the oracle; statistics in f32.  HBM-bound: rows*d*(4 + sizeof(T)).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out, int rows,
+                                                        int d) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = (const float4*)(x + (int64_t)row * d);
+  const int nv = d >> 2;
+  float s = 0.f;
+  for (int i = lane; i < nv; i += 64) { float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    float4 v = xr[i];
+    float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d + 1e-5f);
+  T* o = out + (int64_t)row * d;
+  for (int i = lane; i < nv; i += 64) {
+    float4 v = xr[i], gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
+    float r0 = (v.x - mean) * rstd * gm.x + bt.x, r1 = (v.y - mean) * rstd * gm.y + bt.y;
+    float r2 = (v.z - mean) * rstd * gm.z + bt.z, r3 = (v.w - mean) * rstd * gm.w + bt.w;
+    if constexpr (sizeof(T) == 4) {
+      ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
+    } else {
+      uint2 p;
+      p.x = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+      p.y = (uint32_t)f2bf(r2) | ((uint32_t)f2bf(r3) << 16);
+      ((uint2*)o)[i] = p;
+    }
+  }
+}
+template <typename T>
+void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
+  hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, d);
+}
+template void launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
+template void launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = from_f<T>(in[i]);
+}
+template <typename T>
+__global__ void uncast_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = to_f<T>(in[i]);
+}
+template <typename T> void launch_cast(const float* in, T* out, int64_t n, hipStream_t s) {
+  int64_t nb = (n + 255) / 256; int blocks = (int)(nb < 4096 ? nb : 4096);
+  hipLaunchKernelGGL(cast_kernel<T>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, in, out, n);
+}
+template <typename T> void launch_uncast(const T* in, float* out, int64_t n, hipStream_t s) {
+  int64_t nb = (n + 255) / 256; int blocks = (int)(nb < 4096 ? nb : 4096);
+  hipLaunchKernelGGL(uncast_kernel<T>, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, in, out, n);
+}
+template void launch_cast<float>(const float*, float*, int64_t, hipStream_t);
+template void launch_cast<bf16_t>(const float*, bf16_t*, int64_t, hipStream_t);
+template void launch_uncast<float>(const float*, float*, int64_t, hipStream_t);
+template void launch_uncast<bf16_t>(const bf16_t*, float*, int64_t, hipStream_t);

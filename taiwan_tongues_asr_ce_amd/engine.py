@@ -1,0 +1,193 @@
+"""Thin Python owner of one libttasr context (one GPU, one stream).  numpy in / numpy out; every compute
+method is a single C-ABI call into the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .config import COMPUTE_BF16, COMPUTE_F32, NON_SPEECH_TOKENS_MULTI, SpecialTokens, WhisperDims
+
+
+class TtasrError(RuntimeError):
+    pass
+
+
+@dataclass
+class GenResult:
+    tokens: List[List[int]]
+    sum_logprob: np.ndarray
+    no_speech_prob: np.ndarray
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_suppress(st: SpecialTokens, vocab: int) -> List[int]:
+    """suppress_tokens=[-1] of faster-whisper: non-speech symbols + task/sot/prev/no-speech specials."""
+    ids = [t for t in NON_SPEECH_TOKENS_MULTI if t < min(vocab, st.eot)]
+    ids += [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]
+    return sorted(set(ids))
+
+
+class Engine:
+    def __init__(self, dims: WhisperDims, compute_type: int = COMPUTE_BF16, max_batch: int = 1, device: int = 0):
+        self.lib = _lib.load()
+        self.dims = dims
+        self.compute_type = compute_type
+        self.max_batch = max_batch
+        self.device = device
+        cfg = _lib.Config(dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, dims.enc_layers,
+                          dims.dec_layers, dims.vocab, dims.n_text_ctx, compute_type, max_batch, 0)
+        h = C.c_void_p()
+        rc = self.lib.ttasr_create(C.byref(cfg), device, C.byref(h))
+        if rc != 0:
+            raise TtasrError(f"ttasr_create failed ({rc}): {self.lib.ttasr_last_error(None).decode()}")
+        self.h = h
+        self.special = SpecialTokens.for_vocab(dims.vocab)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise TtasrError(f"{what} failed ({rc}): {self.lib.ttasr_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ttasr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------------
+    def load_weights(self, tensors: Iterable[Tuple[str, np.ndarray]]):
+        for name, arr in tensors:
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            dims = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.ttasr_load_tensor(self.h, name.encode(), _ptr(a), dims, a.ndim), f"load_tensor({name})")
+        self._check(self.lib.ttasr_finalize_weights(self.h), "finalize_weights")
+
+    # -- a5 ------------------------------------------------------------------------------------
+    def log_mel(self, clips: Sequence[np.ndarray], want_output: bool = True) -> Optional[np.ndarray]:
+        B = len(clips)
+        n_win = self.dims.n_frames * 160
+        stride = max(1, min(n_win, max((len(c) for c in clips), default=1)))
+        pcm = np.zeros((B, stride), dtype=np.float32)
+        ns = np.zeros(B, dtype=np.int64)
+        for b, c in enumerate(clips):
+            n = min(len(c), stride)
+            pcm[b, :n] = np.asarray(c[:n], dtype=np.float32)
+            ns[b] = n
+        out = np.empty((B, self.dims.n_mels, self.dims.n_frames), dtype=np.float32) if want_output else None
+        self._check(self.lib.ttasr_log_mel(self.h, _ptr(pcm), stride, ns.ctypes.data_as(C.POINTER(C.c_int64)), B, 0,
+                                           _ptr(out) if want_output else None), "log_mel")
+        return out
+
+    def log_mel_device(self, dev_ptr: int, stride: int, n_samples: Sequence[int]):
+        """PCM already resident in HBM (bench): dev_ptr = device address of float32 [B][stride]."""
+        ns = np.asarray(n_samples, dtype=np.int64)
+        self._check(self.lib.ttasr_log_mel(self.h, C.c_void_p(dev_ptr), stride, ns.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           len(ns), 1, None), "log_mel(device)")
+
+    def set_mel(self, mel: np.ndarray):
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        assert mel.shape[1:] == (self.dims.n_mels, self.dims.n_frames), mel.shape
+        self._check(self.lib.ttasr_set_mel(self.h, _ptr(mel), mel.shape[0]), "set_mel")
+
+    # -- a6..a8 --------------------------------------------------------------------------------
+    def encode(self, B: int, want_output: bool = False) -> Optional[np.ndarray]:
+        out = np.empty((B, self.dims.n_audio_ctx, self.dims.d_model), dtype=np.float32) if want_output else None
+        self._check(self.lib.ttasr_encode(self.h, B, _ptr(out) if want_output else None), "encode")
+        return out
+
+    def set_encoder_output(self, enc: np.ndarray):
+        enc = np.ascontiguousarray(enc, dtype=np.float32)
+        self._check(self.lib.ttasr_set_encoder_output(self.h, _ptr(enc), enc.shape[0]), "set_encoder_output")
+
+    def cross_kv(self, layer: int, which: int, B: int) -> np.ndarray:
+        out = np.empty((B, self.dims.n_heads, self.dims.n_audio_ctx, 64), dtype=np.float32)
+        self._check(self.lib.ttasr_get_cross_kv(self.h, layer, which, B, _ptr(out)), "get_cross_kv")
+        return out
+
+    # -- a9, a10 -------------------------------------------------------------------------------
+    def gen_opts(self, max_new_tokens: int, timestamps: bool, suppress: Optional[Sequence[int]] = None,
+                 begin_suppress: Optional[Sequence[int]] = None, suppress_eot: bool = False, no_speech: bool = True,
+                 sot_index: int = 0, max_initial_timestamp_index: Optional[int] = 50, check_interval: int = 8):
+        st = self.special
+        sup = np.asarray(default_suppress(st, self.dims.vocab) if suppress is None else list(suppress), dtype=np.int32)
+        bsup = np.asarray([220, st.eot] if begin_suppress is None else list(begin_suppress), dtype=np.int32)
+        o = _lib.GenOpts()
+        o.max_new_tokens = max_new_tokens
+        o.eot, o.no_timestamps, o.timestamp_begin = st.eot, st.no_timestamps, st.timestamp_begin
+        o.no_speech = st.no_speech if no_speech else -1
+        o.sot_index = sot_index
+        o.timestamps = int(timestamps)
+        o.max_initial_timestamp_index = -1 if max_initial_timestamp_index is None else max_initial_timestamp_index
+        o.suppress_eot = int(suppress_eot)
+        o.n_suppress, o.n_begin_suppress = len(sup), len(bsup)
+        o.check_interval = check_interval
+        o.suppress = sup.ctypes.data_as(C.POINTER(C.c_int32))
+        o.begin_suppress = bsup.ctypes.data_as(C.POINTER(C.c_int32))
+        o._keep = (sup, bsup)  # keep the arrays alive
+        return o
+
+    def generate(self, prompts: Sequence[Sequence[int]], opts) -> GenResult:
+        B = len(prompts)
+        max_prompt = max(len(p) for p in prompts)
+        pr = np.zeros((B, max_prompt), dtype=np.int32)
+        pl = np.zeros(B, dtype=np.int32)
+        for b, p in enumerate(prompts):
+            pr[b, :len(p)] = p
+            pl[b] = len(p)
+        toks = np.zeros((B, opts.max_new_tokens), dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        lp = np.zeros(B, dtype=np.float32)
+        ns = np.zeros(B, dtype=np.float32)
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        self._check(self.lib.ttasr_generate(self.h, B, pr.ctypes.data_as(i32p), pl.ctypes.data_as(i32p), max_prompt,
+                                            C.byref(opts), toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                            lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate")
+        return GenResult([toks[b, :lens[b]].tolist() for b in range(B)], lp, ns)
+
+    def decode_reset(self, B: int):
+        self._check(self.lib.ttasr_decode_reset(self.h, B), "decode_reset")
+
+    def decode_step(self, tokens: Sequence[int], want_logits: bool = True) -> Optional[np.ndarray]:
+        t = np.asarray(tokens, dtype=np.int32)
+        out = np.empty((len(t), self.dims.vocab), dtype=np.float32) if want_logits else None
+        self._check(self.lib.ttasr_decode_step(self.h, t.ctypes.data_as(C.POINTER(C.c_int32)), len(t),
+                                               _ptr(out) if want_logits else None), "decode_step")
+        return out
+
+    def apply_rules(self, rows: np.ndarray, hist: np.ndarray, opts) -> Tuple[np.ndarray, np.ndarray]:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        hist = np.ascontiguousarray(hist, dtype=np.int32)
+        n = rows.shape[0]
+        out = np.empty_like(rows)
+        choice = np.empty(n, dtype=np.int32)
+        self._check(self.lib.ttasr_apply_rules(self.h, _ptr(rows), hist.ctypes.data_as(C.POINTER(C.c_int32)), hist.shape[1],
+                                               n, C.byref(opts), _ptr(out), choice.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "apply_rules")
+        return out, choice
+
+    # -- measurement ---------------------------------------------------------------------------
+    def phase_ms(self) -> Dict[str, float]:
+        a = (C.c_float * 4)()
+        self._check(self.lib.ttasr_phase_ms(self.h, a), "phase_ms")
+        return dict(mel=a[0], encoder=a[1], cross_kv=a[2], decode=a[3])
+
+    def bench_kernel(self, name: str, B: int, iters: int = 20) -> Dict[str, float]:
+        ms, by, fl = C.c_float(), C.c_double(), C.c_double()
+        self._check(self.lib.ttasr_bench_kernel(self.h, name.encode(), B, iters, C.byref(ms), C.byref(by), C.byref(fl)),
+                    f"bench_kernel({name})")
+        return dict(ms=ms.value, bytes=by.value, flops=fl.value)
+
+    def sync(self):
+        self._check(self.lib.ttasr_sync(self.h), "sync")
