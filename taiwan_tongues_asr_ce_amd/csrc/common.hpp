@@ -73,6 +73,10 @@ bool gemm_bf16_fast_ok(const GemmArgs& g);
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
 
+// decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
+void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s);
+bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s);
+
 // mel
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
                 const float* filters /*[201][n_mels]*/, const float* dft_cos, const float* dft_sin /*[400]*/,

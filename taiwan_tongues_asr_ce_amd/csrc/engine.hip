@@ -26,12 +26,15 @@ struct Slot {              // where one named tensor lands on the device
   int kind = 0;            // 0 matrix->T, 1 vector->f32, 2 conv [out][in][3] -> T [out][3][in], 3 f32 matrix
   float scale = 1.0f;
   bool loaded = false;
+  void* sh_base = nullptr;  // bf16 mode, decoder matrices: fragment-packed copy for the skinny GEMM
+  int sh_row_off = 0;
 };
 
 struct EncLayerW { float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *b1, *b2; void *wqkv, *wo, *w1, *w2; };
 struct DecLayerW {
   float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *bqx, *bkvx, *box, *ln3g, *ln3b, *b1, *b2;
   void *wqkv, *wo, *wqx, *wkvx, *wox, *w1, *w2;
+  void *wqkv_sh = nullptr, *wo_sh = nullptr, *wqx_sh = nullptr, *wox_sh = nullptr, *w1_sh = nullptr, *w2_sh = nullptr;
 };
 
 }  // namespace
@@ -52,7 +55,7 @@ struct ttasr_ctx {
   std::unordered_map<std::string, Slot> slots;
 
   // weights
-  void *conv1_w = nullptr, *conv2_w = nullptr, *emb = nullptr, *dpos = nullptr;
+  void *conv1_w = nullptr, *conv2_w = nullptr, *emb = nullptr, *dpos = nullptr, *emb_sh = nullptr;
   float *conv1_b = nullptr, *conv2_b = nullptr, *epos = nullptr, *elnf_g = nullptr, *elnf_b = nullptr, *dlnf_g = nullptr,
         *dlnf_b = nullptr;
   std::vector<EncLayerW> enc;
@@ -222,6 +225,27 @@ int build_weights(ttasr_ctx* c) {
     TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
   }
   TRY(ln("model.decoder.layer_norm", &c->dlnf_g, &c->dlnf_b));
+  if (c->bf16) {  // fragment-packed copies of every matrix the decode step streams
+    auto packed = [&](const std::string& name, void** base, int64_t rows_total, int64_t K, int row_off) -> int {
+      if (!*base) TRY(alloc_mat(c, base, (rows_total + 15) / 16 * 16 * K));
+      Slot& s = c->slots[name];
+      s.sh_base = *base; s.sh_row_off = row_off;
+      return 0;
+    };
+    TRY(packed("model.decoder.embed_tokens.weight", &c->emb_sh, V, d, 0));
+    for (int i = 0; i < c->cfg.dec_layers; ++i) {
+      std::string p = "model.decoder.layers." + std::to_string(i);
+      DecLayerW& L = c->dec[i];
+      TRY(packed(p + ".self_attn.q_proj.weight", &L.wqkv_sh, 3 * d, d, 0));
+      TRY(packed(p + ".self_attn.k_proj.weight", &L.wqkv_sh, 3 * d, d, d));
+      TRY(packed(p + ".self_attn.v_proj.weight", &L.wqkv_sh, 3 * d, d, 2 * d));
+      TRY(packed(p + ".self_attn.out_proj.weight", &L.wo_sh, d, d, 0));
+      TRY(packed(p + ".encoder_attn.q_proj.weight", &L.wqx_sh, d, d, 0));
+      TRY(packed(p + ".encoder_attn.out_proj.weight", &L.wox_sh, d, d, 0));
+      TRY(packed(p + ".fc1.weight", &L.w1_sh, F, d, 0));
+      TRY(packed(p + ".fc2.weight", &L.w2_sh, d, F, 0));
+    }
+  }
   c->stage_elems = std::max<size_t>((size_t)V * d, (size_t)d * 3 * d);
   c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)F * d);
   TRY(dalloc(c, &c->stage_f32, c->stage_elems * 4, false));
@@ -298,6 +322,15 @@ void gemm(ttasr_ctx* c, const GemmArgs& g) {
   launch_gemm_basic<T>(g, c->stream);
 }
 
+// decode-step GEMM: B rows against a streamed weight; bf16 uses the fragment-packed skinny kernel
+template <typename T>
+void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
+  if constexpr (sizeof(T) == 2) {
+    if (!c->force_basic && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, c->stream)) return;
+  }
+  launch_gemm_basic<T>(g, c->stream);
+}
+
 template <typename T>
 GemmArgs lin_args(const void* A, const void* W, int M, int N, int K) {
   GemmArgs g; g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.epi.ldc = N;
@@ -367,24 +400,24 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
     launch_layernorm<T>(c->dx, L.ln1g, L.ln1b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv; dec_gemm<T>(c, g, L.wqkv_sh); }
     launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
                                (int64_t)l * c->pool_layer_elems, c->st.step, (T*)c->datt, B, c->H, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wo_sh); }
     launch_layernorm<T>(c->dx, L.ln2g, L.ln2b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq; dec_gemm<T>(c, g, L.wqx_sh); }
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
     launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wox_sh); }
     launch_layernorm<T>(c->dx, L.ln3g, L.ln3b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid; gemm<T>(c, g); }
-    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid; dec_gemm<T>(c, g, L.w1_sh); }
+    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.w2_sh); }
   }
   if (mode != 2) {
     launch_layernorm<T>(c->dx, c->dlnf_g, c->dlnf_b, (T*)c->dh, B, d, s);
     GemmArgs g = lin_args<T>(c->dh, c->emb, B, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
     g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-    gemm<T>(c, g);
+    dec_gemm<T>(c, g, c->emb_sh);
   }
   if (mode != 1) launch_select(c->logits, c->st, c->rp, B, nullptr, s);
   launch_advance(c->st.step, s);
@@ -555,6 +588,7 @@ int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const i
     if ((size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
     HIPCHK(c, hipMemcpyAsync(c->stage_f32, src, n * 4, hipMemcpyHostToDevice, c->stream));
     launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
+    if (s.sh_base) launch_shuffle_cast(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));  // src/tmp are caller/stack owned
   s.loaded = true;
@@ -800,7 +834,8 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
   double bytes = 0, flops = 0;
   auto once = [&](void) -> int {
     if (k == "xattn") {
-      const char* Kx = (const char*)c->xkv;
+      static int layer_rr = 0;  // walk the layers: one layer's K/V (246 MB at B=32) would sit in the Infinity Cache
+      const char* Kx = (const char*)c->xkv + (size_t)(layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
       if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
                                                     (bf16_t*)c->datt, B, c->H, c->T, s);
       else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
@@ -820,12 +855,12 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
     } else if (k == "dec_gemm_fc1") {
       GemmArgs g; g.A = c->dh; g.W = c->dec[0].w1; g.M = B; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->dec[0].b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      if (c->bf16) dec_gemm<bf16_t>(c, g, c->dec[0].w1_sh); else dec_gemm<float>(c, g, nullptr);
       bytes = (ffn * d + (double)B * (d + ffn)) * e; flops = 2.0 * B * d * ffn;
     } else if (k == "logits_gemm") {
       GemmArgs g; g.A = c->dh; g.W = c->emb; g.M = B; g.N = c->V; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ldv; g.epi.out_f32 = c->logits;
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      if (c->bf16) dec_gemm<bf16_t>(c, g, c->emb_sh); else dec_gemm<float>(c, g, nullptr);
       bytes = (double)c->V * d * e + (double)B * c->V * 4.0; flops = 2.0 * B * d * c->V;
     } else {
       return fail(c, TTASR_E_INVALID, "unknown kernel '%s'", name);

@@ -1,0 +1,133 @@
+// Decode-time weight-streaming GEMM (bf16): out[b][n] = sum_k x[b][k] * W[n][k] for a handful of rows
+// b <= 64 (one row per sequence in the batch).  HBM-bound on the weights: every weight byte is read once
+// per step for the whole batch (SURVEY.md section 8d "algorithmic bytes per decode step").
+//
+// MI355X-native layout: the decoder weights are re-packed ONCE at load time into MFMA-fragment order so
+// the stream is perfectly coalesced with no LDS staging ("GEMV / M <= 16 decode weights: load straight to
+// VGPRs", cdna_hip_programming.md section 5): for n-block nb (16 output rows) and k-block kb (32 inputs)
+// the 1 KiB at ((nb * K/32 + kb) * 64 + lane) * 16 B holds W[nb*16 + (lane & 15)][kb*32 + 8*(lane >> 4) ..+8],
+// i.e. exactly lane `lane`'s A operand of v_mfma_f32_16x16x32_bf16.  The batch rows are the B operand
+// (x[b = lane & 15][k...], L2-resident), so D = W_tile * x^T with rows = n, cols = b.
+// Workgroup = 4 waves that split this block's K range; partial tiles are summed through LDS.  For the
+// residual GEMMs (out-proj, fc2) a second grid dimension splits K further and the partials are added to
+// the f32 residual stream with global float atomics (x += W h + b is an accumulation already).
+#include "common.hpp"
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+__global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K,
+                                    int row_offset) {
+  // one thread per 16-byte output chunk
+  const int64_t n_chunks = (int64_t)rows * K / 8;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
+    const int kb_per = K / 32;
+    int lane = (int)(c & 63);
+    int64_t blk = c >> 6;
+    int kb = (int)(blk % kb_per);
+    int nb = (int)(blk / kb_per);
+    int r = nb * 16 + (lane & 15);
+    int k = kb * 32 + 8 * (lane >> 4);
+    const float* s = src + (int64_t)r * K + k;
+    uint4 o;
+    o.x = (uint32_t)f2bf(s[0]) | ((uint32_t)f2bf(s[1]) << 16);
+    o.y = (uint32_t)f2bf(s[2]) | ((uint32_t)f2bf(s[3]) << 16);
+    o.z = (uint32_t)f2bf(s[4]) | ((uint32_t)f2bf(s[5]) << 16);
+    o.w = (uint32_t)f2bf(s[6]) | ((uint32_t)f2bf(s[7]) << 16);
+    int64_t dst_blk = ((int64_t)(nb + row_offset / 16) * kb_per + kb) * 64 + lane;
+    ((uint4*)dst)[dst_blk] = o;
+  }
+}
+void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s) {
+  int64_t n_chunks = (int64_t)rows * K / 8;
+  int64_t nb = (n_chunks + 255) / 256;
+  hipLaunchKernelGGL(shuffle_cast_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, dst_base, rows, K,
+                     row_offset);
+}
+
+template <int NB>  // batch blocks of 16 rows
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
+                                                          int B, int N, int K, int ksplit, GemmEpi e) {
+  constexpr int U = 5;
+  __shared__ float red[4][NB][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.x, ks = blockIdx.y;
+  const int kb_per = K / 32;
+  const int steps_per_wave = kb_per / (4 * ksplit);
+  const int kb0 = (ks * 4 + wave) * steps_per_wave;
+  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
+  const bf16_t* xp[NB];
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    int b = min(bb * 16 + (lane & 15), B - 1);
+    xp[bb] = x + (int64_t)b * K + kb0 * 32 + 8 * (lane >> 4);
+  }
+  f32x4 acc[NB];
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (; i + U <= steps_per_wave; i += U) {
+    u32x4 w[U], xv[U][NB];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (int64_t)(i + u) * 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) xv[u][bb] = *(const u32x4*)(xp[bb] + (i + u) * 32);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb)
+        acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u][bb], acc[bb], 0, 0, 0);
+  }
+  for (; i < steps_per_wave; ++i) {
+    u32x4 w = __builtin_nontemporal_load(wp + (int64_t)i * 64);
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      u32x4 xv = *(const u32x4*)(xp[bb] + i * 32);
+      acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w, *(s16x8*)&xv, acc[bb], 0, 0, 0);
+    }
+  }
+  // D layout: col = lane & 15 = batch row, row = (lane >> 4) * 4 + r = output n.  LDS index = b * 16 + n.
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][bb][(lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
+  __syncthreads();
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    float v = (red[0][bb][tid] + red[1][bb][tid]) + (red[2][bb][tid] + red[3][bb][tid]);
+    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
+    if (b < B && n < N) {
+      if (ksplit > 1) {  // accumulate into the f32 residual stream
+        if (ks == 0 && e.bias) v += e.bias[n];
+        atomicAdd(e.out_f32 + (int64_t)b * e.ldc + n, v);
+      } else {
+        if (e.bias) v += e.bias[n];
+        if (e.act == 1) v = gelu_erf(v);
+        const int64_t idx = (int64_t)b * e.ldc + n;
+        if (e.residual) v += e.residual[idx];
+        if (e.out_f32) e.out_f32[idx] = v;
+        if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
+      }
+    }
+  }
+}
+
+// Picks the K split: residual GEMMs (out_f32 == residual, no activation, no T output) may split K across
+// workgroups; the others keep ksplit = 1.  Returns false when the shape does not fit (caller falls back
+// to gemm_basic).
+bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (B < 1 || B > 64 || K % 128 != 0) return false;
+  const int n_blocks = (N + 15) / 16;
+  const int kb_per = K / 32;
+  int ksplit = 1;
+  const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t && !e.rowtab;
+  if (can_split) {
+    while (n_blocks * ksplit < 512 && kb_per % (8 * ksplit) == 0 && kb_per / (8 * ksplit) >= 4) ksplit *= 2;
+  }
+  if (kb_per % (4 * ksplit) != 0) return false;
+  dim3 grid(n_blocks, ksplit);
+  if (B <= 16) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else if (B <= 32) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+  return true;
+}

@@ -1,0 +1,97 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in CPU tests).  Clips are independent units (asr_core.py:151 transcribes file by file), so
+the path shards with no data-path collective: the only exchanges are the one-off weight broadcast from
+rank 0 and the gather of the result token ids."""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import synth
+from .config import WhisperDims
+
+
+def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n_items for `rank`; the first n_items % world ranks get one extra."""
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, np.ndarray]]], device=None,
+                      bucket_bytes: int = 256 << 20) -> Iterator[Tuple[str, np.ndarray]]:
+    """Rank 0 supplies (name, array) in tensor_specs order; every rank yields the same sequence.  Tensors
+    travel in ~256 MB buckets (few, large broadcasts: xGMI is point-to-point, so per-call latency and
+    per-link bandwidth, not switch fan-out, set the cost)."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        yield from src_iter
+        return
+    rank = dist.get_rank()
+    dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
+    specs = synth.tensor_specs(dims)
+    it = iter(src_iter) if rank == 0 else None
+    i = 0
+    while i < len(specs):
+        j, nbytes = i, 0
+        while j < len(specs) and (j == i or nbytes + 4 * int(np.prod(specs[j][1])) <= bucket_bytes):
+            nbytes += 4 * int(np.prod(specs[j][1]))
+            j += 1
+        n_el = nbytes // 4
+        if rank == 0:
+            parts = []
+            for k in range(i, j):
+                name, arr = next(it)
+                assert name == specs[k][0] and tuple(arr.shape) == tuple(specs[k][1]), (name, specs[k])
+                parts.append(np.ascontiguousarray(arr, dtype=np.float32).ravel())
+            flat = torch.from_numpy(np.concatenate(parts)).to(dev)
+        else:
+            flat = torch.empty(n_el, dtype=torch.float32, device=dev)
+        dist.broadcast(flat, src=0)
+        host = flat.cpu().numpy()
+        off = 0
+        for k in range(i, j):
+            n = int(np.prod(specs[k][1]))
+            yield specs[k][0], host[off:off + n].reshape(specs[k][1])
+            off += n
+        i = j
+
+
+def broadcast_weights(engine, dims: WhisperDims, src_iter, device=None):
+    engine.load_weights(broadcast_tensors(dims, src_iter, device))
+
+
+def gather_tokens(tokens: Sequence[Sequence[int]], max_len: int, device=None, pad: int = -1) -> np.ndarray:
+    """All ranks' token ids as one int32 [world * B][max_len] array (padded with `pad`), rank order."""
+    B = len(tokens)
+    local = np.full((B, max_len), pad, dtype=np.int32)
+    for b, t in enumerate(tokens):
+        n = min(len(t), max_len)
+        local[b, :n] = t[:n]
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
+    mine = torch.from_numpy(local).to(dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.cat(out, dim=0).cpu().numpy()
