@@ -374,7 +374,7 @@ int run_encoder(ttasr_ctx* c, int B) {
     const EncLayerW& L = c->enc[l];
     launch_layernorm<T>(c->x, L.ln1g, L.ln1b, (T*)c->h, R, d, s);
     { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
-    if (sizeof(T) == 2 && !c->force_basic && getenv("TTASR_FLASH") != nullptr)
+    if (sizeof(T) == 2 && !c->force_basic && getenv("TTASR_NO_FLASH") == nullptr)
       launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
     else
       launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
@@ -848,7 +848,7 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       bytes = ((double)B * T_ * (d + ffn) + ffn * d) * e; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
       if (c->bf16) {
-        if (!c->force_basic && getenv("TTASR_FLASH")) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
+        if (!c->force_basic && !getenv("TTASR_NO_FLASH")) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
         else launch_enc_attn_simple<bf16_t>((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
       } else launch_enc_attn_simple<float>((const float*)c->qkv, (float*)c->att, B, c->T, c->H, s);
       bytes = (double)B * T_ * 4.0 * d * e; flops = 4.0 * B * T_ * T_ * d;

@@ -186,3 +186,22 @@ def test_tiny_bf16_argmax_consistent(tiny_oracle):
         logits = R.decoder_forward(torch.tensor(nxt)[:, None], cache, xkv, Wb, dims)[:, 0]
     assert worst < 0.12, worst
     e.close()
+
+
+def test_flash_attention_matches_simple_kernel(tiny_oracle):
+    """bf16 encoder with the MFMA flash kernel vs the f32-VALU attention kernel (same bf16 inputs):
+    outputs are LayerNorm-scale (|x| ~ 1..5); tolerance 0.05 max / 0.004 mean absolute (P is rounded to
+    bf16 before the PV product in the flash kernel)."""
+    dims, _, clips, _ = tiny_oracle
+    e = _engine("tiny", COMPUTE_BF16, 4)
+    e.log_mel(clips, want_output=False)
+    a = e.encode(4, want_output=True)
+    os.environ["TTASR_NO_FLASH"] = "1"
+    try:
+        b = e.encode(4, want_output=True)
+    finally:
+        del os.environ["TTASR_NO_FLASH"]
+    assert np.isfinite(a).all()
+    assert np.abs(a - b).max() < 0.05, np.abs(a - b).max()
+    assert np.abs(a - b).mean() < 0.004, np.abs(a - b).mean()
+    e.close()
