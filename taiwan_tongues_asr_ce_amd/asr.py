@@ -1,0 +1,97 @@
+"""Plugin-level drop-in: the reference's ASR adapter interface
+(api/stt_streaming/src/asr/asr_interface.py:1-15, asr_factory.py:9-30, faster_whisper_asr.py:16-303) with
+an MI355X backend registered under "mi355x_whisper" (and answering to "faster_whisper", so the streaming
+server's `ASRFactory.create_asr_pipeline("faster_whisper", ...)` call needs no change)."""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+class ASRInterface:
+    async def transcribe(self, client):
+        raise NotImplementedError("This method should be implemented by subclasses.")
+
+    def warm_up(self):
+        raise NotImplementedError("This method should be implemented by subclasses.")
+
+
+def pcm16_bytes_to_float(buf: bytes) -> np.ndarray:
+    """The streaming client hands over 16 kHz mono s16le bytes (client.py:32-35; audio_utils.py:5-29 wraps
+    them into a wav that faster-whisper decodes to float32 / 32768)."""
+    return np.frombuffer(bytes(buf), dtype="<i2").astype(np.float32) / 32768.0
+
+
+class MI355XWhisperASR(ASRInterface):
+    def __init__(self, **kwargs):
+        from .model import WhisperModel
+        model_size = kwargs.get("model_size", "large-v3-turbo")  # faster_whisper_asr.py:21
+        model_path = kwargs.get("model_path") or model_size
+        device = kwargs.get("device", "cuda")
+        compute_type = kwargs.get("compute_type", "float16")   # api/config.py:11-12
+        self.asr_pipeline = WhisperModel(model_path, device=device, compute_type=compute_type,
+                                         max_batch=kwargs.get("max_batch", 1))
+        # health-check attributes (faster_whisper_asr.py:111-114, streaming_asr.py:455-463)
+        self.device, self.compute_type, self.model_size, self.model_path = device, compute_type, model_size, model_path
+        self.default_transcribe_kwargs = {  # faster_whisper_asr.py:139-149
+            "word_timestamps": False, "vad_filter": True, "beam_size": 5, "condition_on_previous_text": True,
+            "initial_prompt": "繁體中文",
+        }
+        self.text_filter = kwargs.get("text_filter")  # utils.filter_text of the reference, injected by the caller
+
+    async def transcribe(self, client) -> Optional[Dict[str, Any]]:
+        try:
+            audio = pcm16_bytes_to_float(client.scratch_buffer)
+            kw = dict(self.default_transcribe_kwargs)
+            kw["language"] = "zh"  # faster_whisper_asr.py:161
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                segments, info = self.asr_pipeline.transcribe(audio, **kw)
+                segments = list(segments)
+            if len(segments) == 0:
+                return None
+            text = " ".join(getattr(s, "text", "").strip() for s in segments)
+            if self.text_filter is not None:
+                filtered = self.text_filter(text)
+                text = text if filtered is None else filtered
+            words = [w for s in segments if getattr(s, "words", None) for w in s.words]
+            duration = words[-1].end if words else getattr(segments[-1], "end", None)
+            last = getattr(client, "last_start_time", 0) or 0
+            return {  # same keys as faster_whisper_asr.py:240-255
+                "language": getattr(info, "language", None),
+                "language_probability": getattr(info, "language_probability", None),
+                "final": True, "text": text, "duration": duration,
+                "words": [{"word": w.word, "start": (w.start or 0) + last, "end": (w.end or 0) + last,
+                           "probability": w.probability} for w in words],
+            }
+        except Exception as e:  # the reference logs and returns None (faster_whisper_asr.py:260-267)
+            logger.error("transcribe failed: %s", e)
+            return None
+
+    def warm_up(self):
+        wav = os.environ.get("TTASR_WARMUP_WAV")
+        try:
+            if wav and os.path.exists(wav):
+                segs, _ = self.asr_pipeline.transcribe(wav, language="zh", initial_prompt="繁體中文", beam_size=1)
+            else:
+                segs, _ = self.asr_pipeline.transcribe(np.zeros(16000, np.float32), language="zh", beam_size=1)
+            list(segs)
+        except Exception as e:
+            logger.error("warm_up failed: %s", e)
+
+
+class ASRFactory:
+    _registry = {"mi355x_whisper": MI355XWhisperASR, "faster_whisper": MI355XWhisperASR}
+
+    @staticmethod
+    def create_asr_pipeline(type, **kwargs):
+        cls = ASRFactory._registry.get(type)
+        if cls is None:
+            raise ValueError(f"不支援的 ASR 管道類型: {type}。目前只支援 {sorted(ASRFactory._registry)}")
+        return cls(**kwargs)

@@ -1,0 +1,334 @@
+"""`WhisperModel` - the drop-in for `faster_whisper.WhisperModel` on the reference's hot path.
+
+Same constructor and `transcribe()` surface the three reference call sites use
+(asr_core.py:141,159-167; api/file_asr.py:188,457-465; api/stt_streaming/src/asr/faster_whisper_asr.py:107-109,
+170-172): `WhisperModel(path, device=..., compute_type=...)`, `.transcribe(audio, language=, word_timestamps=,
+vad_filter=, beam_size=, condition_on_previous_text=, initial_prompt=) -> (iterable of Segment, TranscriptionInfo)`.
+Host Python does checkpoint reading, tokenisation and the 30-s window loop; everything from PCM to token ids
+is libttasr (HIP).  There is no CPU path: `device="cpu"` raises, as a failed CUDA load does in the reference
+(faster_whisper_asr.py:116-134 then retries on CPU - that retry is out of scope here).
+"""
+from __future__ import annotations
+
+import json
+import os
+import warnings
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import synth
+from .config import (COMPUTE_BF16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
+                     WhisperDims)
+from .tokenizer import load_tokenizer
+
+
+class Word(NamedTuple):
+    start: float
+    end: float
+    word: str
+    probability: float
+
+
+class Segment(NamedTuple):
+    id: int
+    seek: int
+    start: float
+    end: float
+    text: str
+    tokens: List[int]
+    temperature: float
+    avg_logprob: float
+    compression_ratio: float
+    no_speech_prob: float
+    words: Optional[List[Word]]
+
+
+@dataclass
+class TranscriptionInfo:
+    language: str
+    language_probability: float
+    duration: float
+    duration_after_vad: float
+    all_language_probs: Optional[List[Tuple[str, float]]] = None
+    transcription_options: Dict = field(default_factory=dict)
+    vad_options: Optional[Dict] = None
+
+
+_COMPUTE_ALIASES = {
+    "float32": COMPUTE_F32, "fp32": COMPUTE_F32,
+    # the engine's 16-bit type is bf16; fp16 / int8 requests run as bf16 (documented in DESIGN.md)
+    "bfloat16": COMPUTE_BF16, "bf16": COMPUTE_BF16, "float16": COMPUTE_BF16, "fp16": COMPUTE_BF16,
+    "int8_float16": COMPUTE_BF16, "int8_bfloat16": COMPUTE_BF16, "int8": COMPUTE_BF16, "default": COMPUTE_BF16,
+    "auto": COMPUTE_BF16,
+}
+
+# multilingual Whisper language order (tokens sot+1 ...); only the codes the reference can request matter
+LANGUAGES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta no th ur hr bg lt la "
+             "mi ml cy sk te fa lv bn sr az sl kn et mk br eu is hy ne mn bs kk sq sw gl mr pa si km sn yo so af oc ka be "
+             "tg sd gu am yi lo uz fo ht ps tk nn mt sa lb my bo tl mg as tt haw ln ha ba jw su yue").split()
+
+
+def decode_audio(path: str, sampling_rate: int = SAMPLE_RATE) -> np.ndarray:
+    """Path -> mono float32 @16 kHz.  RIFF/WAV PCM only (stdlib `wave`); the reference decodes with
+    librosa / PyAV (asr_core.py:156, faster-whisper decode_audio), neither of which is installed here."""
+    import wave
+    with wave.open(path, "rb") as w:
+        n_ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise ValueError(f"unsupported sample width {width}")
+    if n_ch > 1:
+        x = x.reshape(-1, n_ch).mean(axis=1)
+    if sr != sampling_rate:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(sr, sampling_rate)
+        x = resample_poly(x, sampling_rate // g, sr // g).astype(np.float32)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _read_hf_dir(path: str) -> Tuple[WhisperDims, Iterable[Tuple[str, np.ndarray]]]:
+    with open(os.path.join(path, "config.json"), "r", encoding="utf-8") as f:
+        cfg = json.load(f)
+    dims = WhisperDims(os.path.basename(os.path.normpath(path)), cfg["num_mel_bins"], cfg["max_source_positions"],
+                       cfg["d_model"], cfg["encoder_attention_heads"], cfg["encoder_ffn_dim"], cfg["encoder_layers"],
+                       cfg["decoder_layers"], cfg["vocab_size"], cfg.get("max_target_positions", 448))
+    st_path = os.path.join(path, "model.safetensors")
+    bin_path = os.path.join(path, "pytorch_model.bin")
+
+    def tensors():
+        if os.path.exists(st_path):
+            from safetensors import safe_open
+            with safe_open(st_path, framework="np") as f:
+                for k in f.keys():
+                    if k != "proj_out.weight":
+                        yield k, np.asarray(f.get_tensor(k), dtype=np.float32)
+        elif os.path.exists(bin_path):
+            import torch
+            sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+            for k, v in sd.items():
+                if k != "proj_out.weight":
+                    yield k, v.float().numpy()
+        else:
+            raise FileNotFoundError(f"{path}: neither model.safetensors nor pytorch_model.bin "
+                                    "(CTranslate2 model.bin is not readable yet: SURVEY.md section 8f N1)")
+    return dims, tensors()
+
+
+class WhisperModel:
+    def __init__(self, model_size_or_path: str, device: str = "auto", device_index: int = 0,
+                 compute_type: str = "default", max_batch: int = 1, **_unused):
+        if device not in ("cuda", "auto", "gpu", "hip"):
+            raise RuntimeError(f"device={device!r}: this build has only the MI355X HIP path (no CPU fallback)")
+        if compute_type not in _COMPUTE_ALIASES:
+            raise ValueError(f"unknown compute_type {compute_type!r}")
+        from .engine import Engine  # imports/loads libttasr; raises when the extension is missing
+        self.model_size_or_path = model_size_or_path
+        self.device = "cuda"
+        self.compute_type = compute_type
+        if os.path.isdir(model_size_or_path):
+            dims, tensors = _read_hf_dir(model_size_or_path)
+            self.tokenizer = load_tokenizer(model_size_or_path, dims.vocab)
+        elif model_size_or_path.startswith("synthetic:"):
+            dims = PRESETS[model_size_or_path.split(":", 1)[1]]
+            tensors = synth.iter_weights(dims)
+            self.tokenizer = load_tokenizer(None, dims.vocab)
+        else:
+            raise FileNotFoundError(
+                f"{model_size_or_path!r} is not a local HF Whisper directory (no network for hub ids); use a directory "
+                "with config.json + model.safetensors, or 'synthetic:<preset>' for seeded random weights")
+        self.dims = dims
+        self.engine = Engine(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
+        self.engine.load_weights(tensors)
+        self.special = self.engine.special
+        self.max_batch = max_batch
+        self.is_multilingual = dims.vocab >= 51865
+        self.n_window = dims.n_frames * HOP
+
+    # ------------------------------------------------------------------------------------------
+    def _lang_token(self, language: str) -> int:
+        if not self.is_multilingual:
+            return self.special.lang_zh
+        if language not in LANGUAGES:
+            raise ValueError(f"unknown language {language!r}")
+        return self.special.sot + 1 + LANGUAGES.index(language)
+
+    def detect_language(self, audio: np.ndarray) -> Tuple[str, float, List[Tuple[str, float]]]:
+        """Language = argmax over the language tokens of the logits after <|startoftranscript|>."""
+        eng, st = self.engine, self.special
+        eng.log_mel([audio[: self.n_window]], want_output=False)
+        eng.encode(1)
+        eng.decode_reset(1)
+        logits = eng.decode_step([st.sot])[0]
+        n_lang = (st.translate if st.translate < st.transcribe else st.transcribe) - (st.sot + 1)
+        n_lang = max(1, min(n_lang, len(LANGUAGES)))
+        ll = logits[st.sot + 1: st.sot + 1 + n_lang].astype(np.float64)
+        p = np.exp(ll - ll.max())
+        p /= p.sum()
+        order = np.argsort(-p)
+        probs = [(LANGUAGES[i], float(p[i])) for i in order]
+        return probs[0][0], probs[0][1], probs
+
+    def _prompt(self, lang_tok: int, task: str, without_timestamps: bool, prev: Sequence[int]) -> Tuple[List[int], int]:
+        st = self.special
+        p: List[int] = []
+        if prev:
+            p.append(st.sot_prev)
+            p.extend(list(prev)[-(self.dims.n_text_ctx // 2 - 1):])
+        sot_index = len(p)
+        p.append(st.sot)
+        if self.is_multilingual or True:
+            p.append(lang_tok)
+            p.append(st.translate if task == "translate" else st.transcribe)
+        if without_timestamps:
+            p.append(st.no_timestamps)
+        return p, sot_index
+
+    def _split_segments(self, tokens: List[int], seek: int, n_frames_window: int, time_offset: float,
+                        without_timestamps: bool):
+        """Split one window's tokens on timestamp pairs (openai-whisper / faster-whisper segment rule).
+        Returns (list of (start, end, tokens), frames to advance)."""
+        st = self.special
+        tb = st.timestamp_begin
+        prec = 0.02
+        toks = [t for t in tokens if t != st.eot]
+        is_ts = [t >= tb for t in toks]
+        out = []
+        single_end = len(is_ts) >= 2 and is_ts[-1] and not is_ts[-2]
+        consec = [i for i in range(1, len(toks)) if is_ts[i] and is_ts[i - 1]]
+        if consec and not without_timestamps:
+            slices = list(consec)
+            if single_end:
+                slices.append(len(toks))
+            last = 0
+            for cur in slices:
+                sl = toks[last:cur]
+                if sl:
+                    out.append((time_offset + (sl[0] - tb) * prec, time_offset + (sl[-1] - tb) * prec, sl))
+                last = cur
+            if single_end:
+                advance = n_frames_window
+            else:
+                advance = (toks[last - 1] - tb) * 2  # timestamp units of 20 ms -> 10-ms frames
+        else:
+            dur = n_frames_window * HOP / SAMPLE_RATE
+            ts = [t for t in toks if t >= tb]
+            if ts and ts[-1] != tb and not without_timestamps:
+                dur = (ts[-1] - tb) * prec
+            if toks:
+                out.append((time_offset, time_offset + dur, toks))
+            advance = n_frames_window
+        return out, max(int(advance), 1)
+
+    # ------------------------------------------------------------------------------------------
+    def transcribe(self, audio: Union[str, np.ndarray], language: Optional[str] = None, task: str = "transcribe",
+                   beam_size: int = 5, word_timestamps: bool = False, vad_filter: bool = False,
+                   condition_on_previous_text: bool = True, initial_prompt: Optional[str] = None,
+                   without_timestamps: bool = False, max_new_tokens: Optional[int] = None,
+                   no_speech_threshold: Optional[float] = 0.6, log_prob_threshold: Optional[float] = -1.0,
+                   max_initial_timestamp: float = 1.0, suppress_blank: bool = True, **kwargs
+                   ) -> Tuple[Iterator[Segment], TranscriptionInfo]:
+        if isinstance(audio, str):
+            audio = decode_audio(audio)
+        audio = np.asarray(audio)
+        if audio.ndim != 1:
+            # asr_core.py:156 loads with mono=False; faster-whisper rejects 2-D input the same way
+            raise ValueError(f"audio must be mono float32 [n] @16 kHz, got shape {audio.shape}")
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        if beam_size != 1:
+            warnings.warn("beam search is not implemented yet: decoding greedily (beam_size=1)", stacklevel=2)
+        if vad_filter:
+            warnings.warn("vad_filter=True: no VAD model in this build, the whole clip is treated as speech", stacklevel=2)
+        if word_timestamps:
+            warnings.warn("word_timestamps=True is not implemented: segments carry words=None", stacklevel=2)
+        duration = len(audio) / SAMPLE_RATE
+        if language is None:
+            if self.is_multilingual:
+                language, lang_p, all_p = self.detect_language(audio)
+            else:
+                language, lang_p, all_p = "en", 1.0, None
+        else:
+            lang_p, all_p = 1.0, None
+        info = TranscriptionInfo(language=language, language_probability=lang_p, duration=duration,
+                                 duration_after_vad=duration, all_language_probs=all_p,
+                                 transcription_options=dict(beam_size=1, task=task, without_timestamps=without_timestamps,
+                                                            condition_on_previous_text=condition_on_previous_text,
+                                                            initial_prompt=initial_prompt))
+        return self._generate_segments(audio, language, task, condition_on_previous_text, initial_prompt,
+                                       without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
+                                       max_initial_timestamp, suppress_blank), info
+
+    def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
+                           no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank
+                           ) -> Iterator[Segment]:
+        eng, st = self.engine, self.special
+        lang_tok = self._lang_token(language)
+        n_total = int(np.ceil(len(audio) / HOP)) if len(audio) else 0
+        prev: List[int] = []
+        if initial_prompt:
+            prev.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
+        prompt_reset = 0
+        seek, idx = 0, 0
+        n_win = self.dims.n_frames
+        max_new = max_new_tokens or (self.dims.n_text_ctx // 2)
+        while seek < n_total:
+            chunk = audio[seek * HOP: seek * HOP + self.n_window]
+            win_frames = min(n_win, n_total - seek)
+            eng.log_mel([chunk], want_output=False)
+            eng.encode(1)
+            prompt, sot_index = self._prompt(lang_tok, task, without_timestamps, prev[prompt_reset:])
+            budget = min(max_new, self.dims.n_text_ctx - len(prompt))
+            opts = eng.gen_opts(budget, timestamps=not without_timestamps, sot_index=sot_index,
+                                begin_suppress=[220, st.eot] if suppress_blank else [],
+                                max_initial_timestamp_index=int(round(max_initial_timestamp / 0.02)), check_interval=4)
+            res = eng.generate([prompt], opts)
+            toks = res.tokens[0]
+            n_tok = max(len(toks), 1)
+            avg_lp = float(res.sum_logprob[0]) / n_tok
+            ns = float(res.no_speech_prob[0])
+            time_offset = seek * HOP / SAMPLE_RATE
+            if no_speech_threshold is not None and ns > no_speech_threshold and \
+                    (log_prob_threshold is None or avg_lp < log_prob_threshold):
+                seek += win_frames  # silent window: skip it entirely
+                continue
+            segs, advance = self._split_segments(toks, seek, win_frames, time_offset, without_timestamps)
+            text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
+            cr = (len(text_all.encode("utf-8")) / max(1, len(zlib.compress(text_all.encode("utf-8"))))) if text_all else 0.0
+            for (s0, s1, stoks) in segs:
+                text = self.tokenizer.decode([t for t in stoks if t < st.eot])
+                if s0 == s1 or not text.strip():
+                    continue
+                yield Segment(idx, seek, round(s0, 3), round(min(s1, time_offset + win_frames * HOP / SAMPLE_RATE), 3), text,
+                              list(stoks), 0.0, avg_lp, cr, ns, None)
+                idx += 1
+            prev.extend(t for t in toks if t < st.eot)
+            if not condition:
+                prompt_reset = len(prev)  # faster-whisper's prompt_reset_since: nothing carries over
+            seek += min(advance, win_frames) if advance > 0 else win_frames
+
+    # ------------------------------------------------------------------------------------------
+    def transcribe_batch(self, clips: Sequence[np.ndarray], language: str = "zh", task: str = "transcribe",
+                         without_timestamps: bool = True, max_new_tokens: int = 224) -> List[List[int]]:
+        """Batched single-window path (clips <= 30 s each): one engine pass for up to max_batch clips.
+        Returns the sampled token ids per clip.  This is the unit the data-parallel layer shards."""
+        eng = self.engine
+        out: List[List[int]] = []
+        lang_tok = self._lang_token(language)
+        for i in range(0, len(clips), self.max_batch):
+            chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + self.max_batch]]
+            eng.log_mel(chunk, want_output=False)
+            eng.encode(len(chunk))
+            prompt, sot_index = self._prompt(lang_tok, task, without_timestamps, [])
+            opts = eng.gen_opts(min(max_new_tokens, self.dims.n_text_ctx - len(prompt)), timestamps=not without_timestamps,
+                                sot_index=sot_index)
+            out.extend(eng.generate([prompt] * len(chunk), opts).tokens)
+        return out

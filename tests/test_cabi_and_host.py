@@ -1,0 +1,144 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol include/ttasr.h declares,
+fails loudly without a GPU, and the host-side logic around it (prompt building, segment splitting,
+sharding, tokenizer stub, adapter registry)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from taiwan_tongues_asr_ce_amd import _lib
+from taiwan_tongues_asr_ce_amd.config import PRESETS, SpecialTokens
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ttasr.h")).read()
+    declared = sorted(set(re.findall(r"\b(ttasr_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.SYMBOLS)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert getattr(raw, s) is not None
+    assert b"gfx950" in lib.ttasr_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(_lib.Config) == 12 * 4
+    assert ctypes.sizeof(_lib.GenOpts) == 12 * 4 + 2 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_create_rejects_bad_geometry_and_no_gpu(lib):
+    import torch
+    h = ctypes.c_void_p()
+    bad = _lib.Config(80, 1500, 384, 5, 1536, 4, 4, 51865, 448, 1, 1, 0)  # head_dim != 64
+    assert lib.ttasr_create(ctypes.byref(bad), 0, ctypes.byref(h)) == -1
+    assert b"head_dim" in lib.ttasr_last_error(None)
+    if not torch.cuda.is_available():
+        d = PRESETS["micro"]
+        ok = _lib.Config(d.n_mels, d.n_audio_ctx, d.d_model, d.n_heads, d.ffn_dim, d.enc_layers, d.dec_layers, d.vocab,
+                         d.n_text_ctx, 1, 1, 0)
+        rc = lib.ttasr_create(ctypes.byref(ok), 0, ctypes.byref(h))
+        assert rc == -2 and not h.value  # TTASR_E_HIP: fails loudly, no CPU fallback
+        assert b"no CPU fallback" in lib.ttasr_last_error(None) or b"HIP" in lib.ttasr_last_error(None)
+        from taiwan_tongues_asr_ce_amd.model import WhisperModel
+        with pytest.raises(RuntimeError):
+            WhisperModel("synthetic:micro", device="cuda")
+        with pytest.raises(RuntimeError):
+            WhisperModel("synthetic:micro", device="cpu")
+
+
+def _bare_model(preset="tiny"):
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    m = object.__new__(WhisperModel)
+    m.dims = PRESETS[preset]
+    m.special = SpecialTokens.for_vocab(m.dims.vocab)
+    m.is_multilingual = True
+    return m
+
+
+def test_prompt_building():
+    m = _bare_model()
+    st = m.special
+    p, sot = m._prompt(st.lang_zh, "transcribe", False, [])
+    assert p == [st.sot, st.lang_zh, st.transcribe] and sot == 0
+    p, sot = m._prompt(st.lang_zh, "transcribe", True, list(range(1000, 1300)))
+    assert p[0] == st.sot_prev and sot == 1 + 223 and p[sot] == st.sot and p[-1] == st.no_timestamps
+    assert p[1:sot] == list(range(1300 - 223, 1300))  # at most n_text_ctx/2 - 1 previous tokens
+    assert m._lang_token("zh") == 50260 and m._lang_token("en") == 50259
+
+
+def test_split_segments_on_timestamp_pairs():
+    m = _bare_model()
+    tb, eot = m.special.timestamp_begin, m.special.eot
+    toks = [tb + 0, 11, 12, tb + 100, tb + 100, 13, tb + 250, tb + 250, eot]
+    segs, adv = m._split_segments(toks, 0, 3000, 0.0, False)
+    assert [(round(a, 2), round(b, 2), t) for a, b, t in segs] == [
+        (0.0, 2.0, [tb, 11, 12, tb + 100]), (2.0, 5.0, [tb + 100, 13, tb + 250])]
+    assert adv == 500  # 5.0 s -> 500 frames
+    # single trailing timestamp: the window is consumed whole
+    segs, adv = m._split_segments([tb, 11, tb + 50, tb + 50, 12, tb + 700, eot], 0, 3000, 30.0, False)
+    assert adv == 3000 and len(segs) == 2 and round(segs[1][1], 2) == 44.0
+    # no timestamps at all
+    segs, adv = m._split_segments([11, 12, eot], 0, 1000, 0.0, True)
+    assert adv == 1000 and segs == [(0.0, 10.0, [11, 12])]
+    assert m._split_segments([eot], 0, 3000, 0.0, False) == ([], 3000)
+
+
+def test_shard_range_covers_everything():
+    from taiwan_tongues_asr_ce_amd.dist import shard_range
+    for n in (0, 1, 7, 32, 256, 257):
+        for w in (1, 2, 3, 8):
+            parts = [shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_tokenizer_stub_and_pcm_conversion():
+    from taiwan_tongues_asr_ce_amd.asr import ASRFactory, pcm16_bytes_to_float
+    from taiwan_tongues_asr_ce_amd.tokenizer import load_tokenizer
+    tk = load_tokenizer(None, 51865)
+    assert tk.decode(tk.encode("繁體中文 abc")) == "繁體中文 abc"
+    assert tk.decode([50257, 50364]) == ""
+    x = pcm16_bytes_to_float(np.array([0, 16384, -32768], dtype="<i2").tobytes())
+    np.testing.assert_array_equal(x, np.array([0.0, 0.5, -1.0], dtype=np.float32))
+    with pytest.raises(ValueError):
+        ASRFactory.create_asr_pipeline("whisper_cpp")
+
+
+def test_decode_audio_wav(tmp_path):
+    import wave
+    from taiwan_tongues_asr_ce_amd.model import decode_audio
+    sr = 44100
+    t = np.arange(sr) / sr
+    st = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], axis=1)
+    p = str(tmp_path / "a.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes((st * 20000).astype("<i2").tobytes())
+    x = decode_audio(p)
+    assert x.dtype == np.float32 and abs(len(x) - 16000) <= 1
+    f = np.fft.rfft(x[:16000] * np.hanning(len(x[:16000])))
+    assert abs(int(np.argmax(np.abs(f))) - 440) <= 1
+
+
+def test_synth_weights_are_order_independent():
+    from taiwan_tongues_asr_ce_amd import synth
+    d = PRESETS["micro"]
+    specs = synth.tensor_specs(d)
+    # HF's state dict has 90 entries / 818432 parameters for this geometry: ours omits the tied proj_out.weight
+    assert len(specs) == 89 and sum(int(np.prod(s)) for _, s, _ in specs) == 818432
+    a = synth.make_tensor(*specs[7])
+    b = dict(synth.iter_weights(d))[specs[7][0]]
+    np.testing.assert_array_equal(a, b)
+    assert synth.noise_clip(3)[:4].tolist() == synth.noise_clip(3, 100)[:4].tolist()

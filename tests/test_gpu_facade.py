@@ -1,0 +1,90 @@
+"""GPU: the reference-shaped surfaces (WhisperModel.transcribe, ASRInterface adapter) over the HIP engine."""
+import asyncio
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import PRESETS
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    return WhisperModel("synthetic:tiny", device="cuda", compute_type="float32", max_batch=4)
+
+
+def test_transcribe_signature_of_the_reference_call_sites(model):
+    audio = synth.noise_clip(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        # exactly the kwargs of asr_core.py:159-167
+        segments, info = model.transcribe(audio, language="zh", word_timestamps=False, vad_filter=True, beam_size=5,
+                                          condition_on_previous_text=True, initial_prompt="")
+        assert any("beam" in str(x.message) for x in w) and any("vad" in str(x.message).lower() for x in w)
+    assert info.language == "zh" and info.language_probability == 1.0 and abs(info.duration - 30.0) < 1e-6
+    assert hasattr(segments, "__next__")  # lazy, like faster-whisper's generator
+    segs = list(segments)
+    assert all(hasattr(s, a) for s in segs for a in ("text", "start", "end", "words", "tokens", "avg_logprob"))
+    assert all(0.0 <= s.start <= s.end <= 30.0 for s in segs)
+    # first-window tokens == the oracle's greedy tokens for the same prompt / rules
+    dims = R.Dims(**PRESETS["tiny"].as_dict())
+    W = R.to_torch(synth.state_dict(PRESETS["tiny"]))
+    st = model.special
+    enc = R.encoder_forward(torch.from_numpy(R.log_mel(audio, 80))[None], W, dims)
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
+    ref = R.greedy_decode(enc, [st.sot, st.lang_zh, st.transcribe], W, dims, rules, 224)
+    got = [t for s in segs for t in s.tokens]
+    ref_toks = [t for t in ref.tokens[0] if t != st.eot]
+    assert got == ref_toks[: len(got)] and len(got) > 0
+
+
+def test_transcribe_errors_and_inputs(model, tmp_path):
+    with pytest.raises(ValueError):
+        model.transcribe(np.zeros((2, 16000), np.float32), language="zh", beam_size=1)
+    segs, info = model.transcribe(np.zeros(0, np.float32), language="zh", beam_size=1)
+    assert list(segs) == [] and info.duration == 0.0
+    import wave
+    p = str(tmp_path / "x.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((synth.noise_clip(2, 48000) * 32767).astype("<i2").tobytes())
+    segs, info = model.transcribe(p, beam_size=1)  # path input + language detection
+    assert info.language in ("en", "zh") or len(info.language) <= 3
+    assert 0.0 < info.language_probability <= 1.0 and abs(info.duration - 3.0) < 1e-3
+    list(segs)
+
+
+def test_long_audio_windows_advance(model):
+    audio = np.concatenate([synth.noise_clip(7), synth.noise_clip(8, 160000)])  # 40 s -> >= 2 windows
+    segs, info = model.transcribe(audio, language="zh", beam_size=1, without_timestamps=True)
+    segs = list(segs)
+    assert len({s.seek for s in segs}) >= 2 and segs[-1].end <= 40.0 + 1e-6
+
+
+def test_batch_path_equals_single(model):
+    clips = [synth.noise_clip(i) for i in range(3)] + [synth.noise_clip(9, 50000)]
+    batch = model.transcribe_batch(clips, max_new_tokens=12)
+    for c, want in zip(clips, batch):
+        assert model.transcribe_batch([c], max_new_tokens=12)[0] == want
+
+
+def test_asr_adapter_result_dict():
+    from taiwan_tongues_asr_ce_amd.asr import ASRFactory
+    asr = ASRFactory.create_asr_pipeline("faster_whisper", model_size="synthetic:tiny", compute_type="float16")
+    assert (asr.device, asr.compute_type, asr.model_size) == ("cuda", "float16", "synthetic:tiny")
+    pcm = (synth.noise_clip(4, 48000) * 32767).astype("<i2").tobytes()
+    client = types.SimpleNamespace(scratch_buffer=bytearray(pcm), client_id="c1", last_start_time=1.5,
+                                   get_file_name=lambda: "c1_0.wav")
+    out = asyncio.run(asr.transcribe(client))
+    assert out is None or set(out) == {"language", "language_probability", "final", "text", "duration", "words"}
+    asr.warm_up()
