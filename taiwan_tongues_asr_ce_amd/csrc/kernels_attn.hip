@@ -103,17 +103,21 @@ template <> struct RowVec<bf16_t> {
 // decoder self-attention with paged KV cache.
 // Pool layout per layer: [page][2 (K,V)][H][PAGE=16 tokens][64]; page_table[b][i] = page of tokens
 // 16i..16i+15 of row b (beam search re-indexes pages instead of copying the cache).
-// One wave per (b, h): appends this step's k,v at position pos = *step, then attends over pos+1 keys.
+// One workgroup (4 waves) per (b, h): appends this step's k,v at position pos = *step, then attends
+// over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
 
 template <typename T>
-__global__ __launch_bounds__(64) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
-                                                              const int32_t* __restrict__ page_table, int pages_per_seq,
-                                                              const int32_t* __restrict__ step, T* __restrict__ out, int H) {
+__global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
+                                                               const int32_t* __restrict__ page_table, int pages_per_seq,
+                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
+  constexpr int UNROLL = 4;
   __shared__ float sc[448 + 64];
-  const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+  __shared__ float part[4][64];
+  __shared__ float red[8];
+  const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64, pos = *step;
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
   const int sub = lane % LPR, rin = lane / LPR;
@@ -121,34 +125,40 @@ __global__ __launch_bounds__(64) void self_attn_decode_kernel(const T* __restric
   RowVec<T>::load(qp + sub * VEC, q);
   RowVec<T>::load(qp + d + sub * VEC, kn);
   RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
-  // append (lanes of row-slot 0 write the new k and v)
-  {
-    int page = page_table[b * pages_per_seq + pos / PAGE];
+  const int32_t* pt = page_table + b * pages_per_seq;
+  if (wave == 0 && rin == 0) {  // append this step's k, v
+    const int page = pt[pos / PAGE];
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
     T* vdst = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (pos % PAGE)) * 64;
-    if (rin == 0) {
-      *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
-      *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
-    }
+    *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
+    *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
   }
-  // scores for cached keys 0..pos-1 (the new key is handled from registers)
+  // cached keys 0..pos-1: row t = (it*4 + wave)*RPI + rin; the new key/value come from registers
+  const int n_it = (pos + 4 * RPI - 1) / (4 * RPI);
   float mloc = -1e30f;
-  for (int t0 = 0; t0 < pos; t0 += RPI) {
-    int t = t0 + rin;
-    float s = 0.f;
-    if (t < pos) {
-      int page = page_table[b * pages_per_seq + t / PAGE];
-      const T* kp = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (t % PAGE)) * 64 + sub * VEC;
-      float kv[VEC];
-      RowVec<T>::load(kp, kv);
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    float kv[UNROLL][VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[j], s);
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      const int tc = min(t, pos - 1);  // always load (clamped): no branch around the load, loads stay in flight together
+      const int page = pt[tc / PAGE];
+      RowVec<T>::load(pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (tc % PAGE)) * 64 + sub * VEC, kv[u]);
     }
 #pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
-    if (t < pos) {
-      if (sub == 0) sc[t] = s;
-      mloc = fmaxf(mloc, s);
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      float s = 0.f;
+      if (t < pos) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[u][j], s);
+      }
+#pragma unroll
+      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+      if (t < pos) {
+        if (sub == 0) sc[t] = s;
+        mloc = fmaxf(mloc, s);
+      }
     }
   }
   float snew = 0.f;
@@ -156,30 +166,41 @@ __global__ __launch_bounds__(64) void self_attn_decode_kernel(const T* __restric
   for (int j = 0; j < VEC; ++j) snew = fmaf(q[j], kn[j], snew);
 #pragma unroll
   for (int o = 1; o < LPR; o <<= 1) snew += __shfl_xor(snew, o);
-  const float mx = fmaxf(wave_max(mloc), snew);
+  mloc = wave_max(mloc);
+  if (lane == 0) red[wave] = mloc;
   __syncthreads();
+  const float mx = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), snew);
   float lsum = 0.f;
-  for (int t = lane; t < pos; t += 64) {
+  for (int t = tid; t < pos; t += 256) {
     float p = __expf(sc[t] - mx);
     sc[t] = p;
     lsum += p;
   }
-  const float pnew = __expf(snew - mx);
-  const float denom = wave_sum(lsum) + pnew;
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
+  const float pnew = __expf(snew - mx);
+  const float denom = (red[4] + red[5]) + (red[6] + red[7]) + pnew;
   float acc[VEC];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = (rin == 0) ? pnew * vn[j] : 0.f;
-  for (int t0 = 0; t0 < pos; t0 += RPI) {
-    int t = t0 + rin;
-    if (t < pos) {
-      int page = page_table[b * pages_per_seq + t / PAGE];
-      const T* vp = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (t % PAGE)) * 64 + sub * VEC;
-      float vv[VEC];
-      RowVec<T>::load(vp, vv);
-      float p = sc[t];
+  for (int j = 0; j < VEC; ++j) acc[j] = (wave == 0 && rin == 0) ? pnew * vn[j] : 0.f;
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    float vv[UNROLL][VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vv[j], acc[j]);
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      const int tc = min(t, pos - 1);
+      const int page = pt[tc / PAGE];
+      RowVec<T>::load(pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (tc % PAGE)) * 64 + sub * VEC, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      if (t < pos) {
+        const float p = sc[t];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vv[u][j], acc[j]);
+      }
     }
   }
 #pragma unroll
@@ -188,16 +209,19 @@ __global__ __launch_bounds__(64) void self_attn_decode_kernel(const T* __restric
     for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
   }
   if (rin == 0) {
-    T* op = out + (int64_t)b * d + h * 64 + sub * VEC;
-    const float inv = 1.0f / denom;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) op[j] = from_f<T>(acc[j] * inv);
+    for (int j = 0; j < VEC; ++j) part[wave][sub * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
   }
 }
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                              const int32_t* step, T* out, int B, int H, hipStream_t s) {
-  hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(64), 0, s, qkv, kv_pool + pool_layer_off, page_table,
+  hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
                      pages_per_seq, step, out, H);
 }
 template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, const int32_t*, float*, int,
@@ -218,7 +242,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
                                                                 const T* __restrict__ V, T* __restrict__ out, int H, int Tk) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
-  constexpr int UNROLL = 4;
+  constexpr int UNROLL = 8;
   extern __shared__ float sc[];  // [Tk] scores, then [4][64] partial outputs, [8] reductions
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      if (t < Tk) RowVec<T>::load(Kp + (int64_t)t * 64 + sub * VEC, kv[u]);
+      RowVec<T>::load(Kp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      if (t < Tk) RowVec<T>::load(Vp + (int64_t)t * 64 + sub * VEC, vv[u]);
+      RowVec<T>::load(Vp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {

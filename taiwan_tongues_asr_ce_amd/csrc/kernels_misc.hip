@@ -140,10 +140,11 @@ template void launch_mel_transpose<float>(const float*, float*, int, int, int, h
 template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm (eps 1e-5), f32 residual stream in -> T out.  One wave per row, float4 loads, two-pass
-// variance (mean first) exactly as the oracle; statistics in f32.  HBM-bound: rows*d*(4 + sizeof(T)).
+// LayerNorm (eps 1e-5), f32 residual stream in -> T out.  One wave per row; the row is read ONCE into
+// registers (d <= 1280), then mean and the two-pass variance (as the oracle) come from registers.
+// HBM-bound: rows*d*(4 + sizeof(T)) bytes.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NV>  // NV = float4 per lane kept in registers: d <= 256 * NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out, int rows,
                                                         int d) {
@@ -151,34 +152,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (row >= rows) return;
   const float4* xr = (const float4*)(x + (int64_t)row * d);
   const int nv = d >> 2;
+  float4 v[NV];
   float s = 0.f;
-  for (int i = lane; i < nv; i += 64) { float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
   const float mean = wave_sum(s) / d;
   float q = 0.f;
-  for (int i = lane; i < nv; i += 64) {
-    float4 v = xr[i];
-    float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
-    q += (a * a + b * b) + (c * c + e * e);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    if (lane + 64 * j < nv) {
+      float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
   }
   const float rstd = rsqrtf(wave_sum(q) / d + 1e-5f);
   T* o = out + (int64_t)row * d;
-  for (int i = lane; i < nv; i += 64) {
-    float4 v = xr[i], gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
-    float r0 = (v.x - mean) * rstd * gm.x + bt.x, r1 = (v.y - mean) * rstd * gm.y + bt.y;
-    float r2 = (v.z - mean) * rstd * gm.z + bt.z, r3 = (v.w - mean) * rstd * gm.w + bt.w;
-    if constexpr (sizeof(T) == 4) {
-      ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
-    } else {
-      uint2 p;
-      p.x = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
-      p.y = (uint32_t)f2bf(r2) | ((uint32_t)f2bf(r3) << 16);
-      ((uint2*)o)[i] = p;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      float4 gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
+      float r0 = (v[j].x - mean) * rstd * gm.x + bt.x, r1 = (v[j].y - mean) * rstd * gm.y + bt.y;
+      float r2 = (v[j].z - mean) * rstd * gm.z + bt.z, r3 = (v[j].w - mean) * rstd * gm.w + bt.w;
+      if constexpr (sizeof(T) == 4) {
+        ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
+      } else {
+        uint2 p;
+        p.x = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+        p.y = (uint32_t)f2bf(r2) | ((uint32_t)f2bf(r3) << 16);
+        ((uint2*)o)[i] = p;
+      }
     }
   }
 }
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
-  hipLaunchKernelGGL(layernorm_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, d);
+  dim3 grid((rows + 3) / 4), block(256);
+  if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, gamma, beta, out, rows, d);
+  else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, gamma, beta, out, rows, d);
+  else if (d <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, gamma, beta, out, rows, d);
+  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, gamma, beta, out, rows, d);
+  else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, gamma, beta, out, rows, d);
 }
 template void launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);

@@ -303,12 +303,13 @@ class WhisperModel:
             segs, advance = self._split_segments(toks, seek, win_frames, time_offset, without_timestamps)
             text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
             cr = (len(text_all.encode("utf-8")) / max(1, len(zlib.compress(text_all.encode("utf-8"))))) if text_all else 0.0
+            limit = time_offset + win_frames * HOP / SAMPLE_RATE  # never report times past the audio that exists
             for (s0, s1, stoks) in segs:
                 text = self.tokenizer.decode([t for t in stoks if t < st.eot])
-                if s0 == s1 or not text.strip():
+                s0, s1 = min(s0, limit), min(s1, limit)
+                if s0 >= s1 or not text.strip():
                     continue
-                yield Segment(idx, seek, round(s0, 3), round(min(s1, time_offset + win_frames * HOP / SAMPLE_RATE), 3), text,
-                              list(stoks), 0.0, avg_lp, cr, ns, None)
+                yield Segment(idx, seek, round(s0, 3), round(s1, 3), text, list(stoks), 0.0, avg_lp, cr, ns, None)
                 idx += 1
             prev.extend(t for t in toks if t < st.eot)
             if not condition:

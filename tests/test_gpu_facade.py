@@ -43,7 +43,7 @@ def test_transcribe_signature_of_the_reference_call_sites(model):
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
     ref = R.greedy_decode(enc, [st.sot, st.lang_zh, st.transcribe], W, dims, rules, 224)
-    got = [t for s in segs for t in s.tokens]
+    got = [t for s in segs if s.seek == 0 for t in s.tokens]  # first 30-s window
     ref_toks = [t for t in ref.tokens[0] if t != st.eot]
     assert got == ref_toks[: len(got)] and len(got) > 0
 
