@@ -76,6 +76,8 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, T* 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
 void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s);
 bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s);
+bool launch_gemm_skinny_ln(const bf16_t* Wsh, const float* xf, const float* gamma, const float* beta, int B, int N, int K,
+                           const GemmEpi& e, hipStream_t s);
 
 // mel
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,

@@ -48,6 +48,7 @@ struct ttasr_ctx {
   bool finalized = false;
   bool force_basic = false;
   bool use_graph = true;
+  bool no_ln_fuse = false;
   size_t esz = 4;  // sizeof(T)
   int T = 0, F = 0, d = 0, H = 0, ffn = 0, V = 0, ldv = 0, M = 0, maxB = 0, n_samples = 0;
   int pages_per_seq = 0;
@@ -331,6 +332,17 @@ void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
   launch_gemm_basic<T>(g, c->stream);
 }
 
+// LayerNorm(x) followed by a decode GEMM; bf16 fuses both into one launch
+template <typename T>
+void dec_ln_gemm(ttasr_ctx* c, const float* g_, const float* b_, int B, const GemmArgs& g, const void* Wsh) {
+  if constexpr (sizeof(T) == 2) {
+    if (!c->force_basic && !c->no_ln_fuse && Wsh &&
+        launch_gemm_skinny_ln((const bf16_t*)Wsh, c->dx, g_, b_, B, g.N, g.K, g.epi, c->stream)) return;
+  }
+  launch_layernorm<T>(c->dx, g_, b_, (T*)c->dh, B, c->d, c->stream);
+  dec_gemm<T>(c, g, Wsh);
+}
+
 template <typename T>
 GemmArgs lin_args(const void* A, const void* W, int M, int N, int K) {
   GemmArgs g; g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.epi.ldc = N;
@@ -399,25 +411,24 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
   launch_embed<T>(c->st.cur_tok, c->st.step, (const T*)c->emb, (const T*)c->dpos, c->dx, B, d, s);
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
-    launch_layernorm<T>(c->dx, L.ln1g, L.ln1b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv; dec_gemm<T>(c, g, L.wqkv_sh); }
+    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv;
+      dec_ln_gemm<T>(c, L.ln1g, L.ln1b, B, g, L.wqkv_sh); }
     launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
                                (int64_t)l * c->pool_layer_elems, c->st.step, (T*)c->datt, B, c->H, s);
     { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wo_sh); }
-    launch_layernorm<T>(c->dx, L.ln2g, L.ln2b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq; dec_gemm<T>(c, g, L.wqx_sh); }
+    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq;
+      dec_ln_gemm<T>(c, L.ln2g, L.ln2b, B, g, L.wqx_sh); }
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
     launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, s);
     { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wox_sh); }
-    launch_layernorm<T>(c->dx, L.ln3g, L.ln3b, (T*)c->dh, B, d, s);
-    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid; dec_gemm<T>(c, g, L.w1_sh); }
+    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid;
+      dec_ln_gemm<T>(c, L.ln3g, L.ln3b, B, g, L.w1_sh); }
     { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.w2_sh); }
   }
   if (mode != 2) {
-    launch_layernorm<T>(c->dx, c->dlnf_g, c->dlnf_b, (T*)c->dh, B, d, s);
     GemmArgs g = lin_args<T>(c->dh, c->emb, B, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
     g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-    dec_gemm<T>(c, g, c->emb_sh);
+    dec_ln_gemm<T>(c, c->dlnf_g, c->dlnf_b, B, g, c->emb_sh);
   }
   if (mode != 1) launch_select(c->logits, c->st, c->rp, B, nullptr, s);
   launch_advance(c->st.step, s);
@@ -531,6 +542,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->n_samples = c->F * 160;
   c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
+  c->no_ln_fuse = getenv("TTASR_LN_FUSE") == nullptr;  // fused LN+GEMM measured slower (r1: +1 ms/step); opt-in
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
   if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));

@@ -131,3 +131,132 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
   else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
   return true;
 }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm fused into the skinny GEMM: out = act(LN(x) W^T + b).  Every decode-step kernel costs one
+// dependent memory round trip plus a launch boundary whatever its size (a 1-thread kernel measures 4 us
+// under rocprofv3), so the 3 LayerNorms per decoder layer are folded into the GEMM that consumes them.
+// Each workgroup normalises all B rows itself (x is B*K*4 <= 160 KB, L2-resident; every wave owns whole
+// rows, so the statistics are wave-local: mean, then two-pass variance from registers, as the oracle) and
+// keeps the bf16 image [B][K] in LDS as the MFMA B operand.  The wave's weight fragments are requested
+// BEFORE the prologue, so their HBM latency hides behind it.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(const bf16_t* __restrict__ Wsh, const float* __restrict__ xf,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int B, int N, int K, GemmEpi e) {
+  constexpr int MAXS = 10, NV = 5, ROWS = NB * 16, RPW = ROWS / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int stride = K * 2 + 16;  // bytes per x row in LDS (+16: spreads the 16 rows of a fragment over the banks)
+  float* red = (float*)(smem + ROWS * stride);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.x;
+  const int kb_per = K / 32;
+  const int steps = kb_per / 4;  // per wave
+  const int kb0 = wave * steps;
+  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
+  u32x4 w[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) w[i] = __builtin_nontemporal_load(wp + (int64_t)min(i, steps - 1) * 64);
+
+  // ---- prologue: LayerNorm of the rows this wave owns -> bf16 LDS image ----
+  const int nv = K >> 2;
+  float4 gm[NV], bt[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = min(lane + 64 * j, nv - 1);
+    gm[j] = ((const float4*)gamma)[i];
+    bt[j] = ((const float4*)beta)[i];
+  }
+#pragma unroll
+  for (int r0 = 0; r0 < RPW; r0 += 4) {
+    float4 v[4][NV];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = min(wave * RPW + r0 + rr, B - 1);
+      const float4* xr = (const float4*)(xf + (int64_t)row * K);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[rr][j] = xr[min(lane + 64 * j, nv - 1)];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < nv) s += (v[rr][j].x + v[rr][j].y) + (v[rr][j].z + v[rr][j].w);
+      const float mean = wave_sum(s) / K;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < nv) {
+          float a = v[rr][j].x - mean, b2 = v[rr][j].y - mean, c = v[rr][j].z - mean, d2 = v[rr][j].w - mean;
+          q += (a * a + b2 * b2) + (c * c + d2 * d2);
+        }
+      const float rstd = rsqrtf(wave_sum(q) / K + 1e-5f);
+      char* dst = smem + (wave * RPW + r0 + rr) * stride;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+          float y0 = (v[rr][j].x - mean) * rstd * gm[j].x + bt[j].x, y1 = (v[rr][j].y - mean) * rstd * gm[j].y + bt[j].y;
+          float y2 = (v[rr][j].z - mean) * rstd * gm[j].z + bt[j].z, y3 = (v[rr][j].w - mean) * rstd * gm[j].w + bt[j].w;
+          uint2 p;
+          p.x = (uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16);
+          p.y = (uint32_t)f2bf(y2) | ((uint32_t)f2bf(y3) << 16);
+          *(uint2*)(dst + i * 8) = p;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- main: D[n][b] += W_frag * x_frag ----
+  f32x4 acc[NB];
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    if (i < steps) {
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const s16x8 xv = *(const s16x8*)(smem + (bb * 16 + (lane & 15)) * stride + (kb0 + i) * 64 + (lane >> 4) * 16);
+        acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[i], xv, acc[bb], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * NB + bb) * 256 + (lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
+  __syncthreads();
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    float v = (red[(0 * NB + bb) * 256 + tid] + red[(1 * NB + bb) * 256 + tid]) +
+              (red[(2 * NB + bb) * 256 + tid] + red[(3 * NB + bb) * 256 + tid]);
+    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
+    if (b < B && n < N) {
+      if (e.bias) v += e.bias[n];
+      if (e.act == 1) v = gelu_erf(v);
+      const int64_t idx = (int64_t)b * e.ldc + n;
+      if (e.out_f32) e.out_f32[idx] = v;
+      if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
+    }
+  }
+}
+
+bool launch_gemm_skinny_ln(const bf16_t* Wsh, const float* xf, const float* gamma, const float* beta, int B, int N, int K,
+                           const GemmEpi& e, hipStream_t s) {
+  if (B < 1 || B > 32 || K % 128 != 0 || K > 1280 || e.residual || e.rowtab) return false;
+  const int NB = B <= 16 ? 1 : 2;
+  const size_t lds = (size_t)NB * 16 * (K * 2 + 16) + (size_t)4 * NB * 256 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_skinny_ln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)gemm_skinny_ln_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  dim3 grid((N + 15) / 16);
+  if (NB == 1) hipLaunchKernelGGL(gemm_skinny_ln_kernel<1>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
+  else hipLaunchKernelGGL(gemm_skinny_ln_kernel<2>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
+  return true;
+}
