@@ -69,6 +69,8 @@ struct GemmArgs {
 template <typename T> void launch_gemm_basic(const GemmArgs& g, hipStream_t s);
 void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s);  // requires M%128==0? no: see kernels_gemm.hip
 bool gemm_bf16_fast_ok(const GemmArgs& g);
+void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s);
+bool gemm_bf16_v2_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);

@@ -318,7 +318,11 @@ int build_workspaces(ttasr_ctx* c) {
 template <typename T>
 void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && g.M >= 256 && gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->stream); return; }
+    if (!c->force_basic && g.M >= 256) {
+      const char* v = getenv("TTASR_GEMM");  // "v1": 128x128 two-stage kernel, default: 256x128 three-stage
+      if (!(v && v[1] == '1') && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->stream); return; }
+      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->stream); return; }
+    }
   }
   launch_gemm_basic<T>(g, c->stream);
 }
@@ -859,6 +863,16 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       g.epi.ldc = c->ffn; g.epi.bias = c->enc[0].b1; g.epi.act = 1; g.epi.out_t = c->mid;
       if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
       bytes = ((double)B * T_ * (d + ffn) + ffn * d) * e; flops = 2.0 * B * T_ * d * ffn;
+    } else if (k == "enc_gemm_qkv") {
+      GemmArgs g; g.A = c->h; g.W = c->enc[0].wqkv; g.M = B * c->T; g.N = 3 * c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
+      g.epi.ldc = 3 * c->d; g.epi.bias = c->enc[0].bqkv; g.epi.out_t = c->qkv;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = ((double)B * T_ * 4 * d + 3 * d * d) * e; flops = 2.0 * B * T_ * d * 3 * d;
+    } else if (k == "enc_gemm_fc2") {
+      GemmArgs g; g.A = c->mid; g.W = c->enc[0].w2; g.M = B * c->T; g.N = c->d; g.K = c->ffn; g.lda = c->ffn; g.ldw = c->ffn;
+      g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2; g.epi.residual = c->x; g.epi.out_f32 = c->x;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = ((double)B * T_ * ffn + ffn * d) * e + 8.0 * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
       if (c->bf16) {
         if (!c->force_basic && !getenv("TTASR_NO_FLASH")) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);

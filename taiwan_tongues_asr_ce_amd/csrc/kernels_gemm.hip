@@ -216,6 +216,164 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmArgs g, int 
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_bf16_v2: 256x128x64 tile, 8 waves (4 along M x 2 along N, 64x64 each), THREE-stage LDS ring filled
+// by global_load_lds with a counted s_waitcnt vmcnt(6) and a raw s_barrier, so the loads of the next
+// k-tile stay in flight across the barrier (guide section 5 "Pipelining across barriers").  One block
+// per CU (144 KiB LDS).  Operands are swapped in the MFMA (A = weight rows, B = activation rows) so each
+// lane ends with 4 CONSECUTIVE output columns of one row: the epilogue stores 8-byte bf16 / 16-byte f32
+// vectors and reads bias as float4.  GELU uses the Abramowitz-Stegun 7.1.26 erf (|err| < 1.5e-7).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erfa = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
+  const float erfx = x < 0.f ? -erfa : erfa;
+  return 0.5f * x * (1.0f + erfx);
+}
+
+// 4 consecutive columns n..n+3 of row m
+__device__ __forceinline__ void epi_store4(const GemmEpi& e, int64_t zoff, int m, int n, f32x4 v) {
+  if (e.bias) {
+    const float4 b = *(const float4*)(e.bias + n);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (e.act == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gelu_fast(v[i]);
+  }
+  if (e.rowtab) {
+    const float4 r = *(const float4*)(e.rowtab + (int64_t)(m % e.rowmod) * e.ldc + n);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  int64_t idx = zoff + (int64_t)m * e.ldc + n;
+  if (e.residual) {
+    const float4 r = *(const float4*)(e.residual + idx);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  if (e.out_f32) *(float4*)(e.out_f32 + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  if (e.out_t) {
+    if (e.headsplit) {
+      const int which = n / e.hs_d, nn = n - which * e.hs_d;
+      const int h = nn >> 6, j = nn & 63;
+      const int b = m / e.hs_T, t = m - b * e.hs_T;
+      idx = (int64_t)which * e.hs_which + (((int64_t)b * e.hs_H + h) * e.hs_T + t) * 64 + j;
+    }
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+    uint2 pk;
+    pk.x = __builtin_bit_cast(uint32_t, lo);
+    pk.y = __builtin_bit_cast(uint32_t, hi);
+    *(uint2*)((bf16_t*)e.out_t + idx) = pk;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;  // 32K + 16K
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16_t* A = (const bf16_t*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
+  const bf16_t* W = (const bf16_t*)g.W;
+
+  const int srow = lane >> 3, sslot = lane & 7;
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = (wave * 4 + p) * 8 + srow;
+    a_src[p] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + ((sslot ^ (row & 7)) << 3);
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wave * 2 + p) * 8 + srow;
+    w_src[p] = W + (int64_t)(n0 + row) * g.ldw + ((sslot ^ (row & 7)) << 3);
+  }
+#define V2_STAGE(buf_, k0_)                                                             \
+  do {                                                                                  \
+    char* base_ = smem + (buf_) * STAGE_BYTES;                                          \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                       \
+        glds16(a_src[p] + (k0_), base_ + (wave * 4 + p) * 1024);                        \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                       \
+        glds16(w_src[p] + (k0_), base_ + A_BYTES + (wave * 2 + p) * 1024);              \
+  } while (0)
+
+  f32x4 acc[4][4];  // [i: m-frag][j: n-frag]; element r = column n0.. + j*16 + (lane>>4)*4 + r of row i*16 + (lane&15)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / BK;
+  V2_STAGE(0, 0);
+  if (nt > 1) V2_STAGE(1, BK);
+  const int fr = lane & 15, fq = lane >> 4;
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nt) {
+      const int nb = cur >= 1 ? cur - 1 : 2;  // (t + 2) % 3
+      V2_STAGE(nb, (t + 2) * BK);
+    }
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr;
+        a[i] = *(const s16x8*)(As + ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
+        const int rb = wn * 64 + i * 16 + fr;
+        b[i] = *(const s16x8*)(Ws + rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+#undef V2_STAGE
+  const int64_t zoff = (int64_t)blockIdx.z * g.epi.batch_stride_c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m < g.M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) epi_store4(g.epi, zoff, m, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+    }
+  }
+}
+
+bool gemm_bf16_v2_ok(const GemmArgs& g) {
+  return g.N % 128 == 0 && g.K % 64 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.epi.ldc % 4 == 0 &&
+         ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
+}
+void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 128;
+  hipLaunchKernelGGL(gemm_bf16_v2_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 3 * 49152, s, g, tiles_m, tiles_n);
+}
+
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
   return g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.M >= 1 &&
          ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0;
