@@ -319,6 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
   V2_STAGE(0, 0);
   if (nt > 1) V2_STAGE(1, BK);
   const int fr = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -328,24 +329,43 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
       const int nb = cur >= 1 ? cur - 1 : 2;  // (t + 2) % 3
       V2_STAGE(nb, (t + 2) * BK);
     }
-    const char* As = smem + cur * STAGE_BYTES;
-    const char* Ws = As + A_BYTES;
+    // All 16 fragment reads are issued first (64 VGPRs) as inline-asm ds_read_b128 with HAND-COUNTED waits:
+    // the k-step-0 MFMAs start once the first 8 reads have landed (lgkmcnt(8)) while the other 8 stream
+    // in behind them.  (hipcc's own placement waits lgkmcnt(0) before the first MFMA: guide 5.7.)
+    s16x8 a[2][4], b[2][4];
+    const uint32_t as_off = lds_base + cur * STAGE_BYTES, ws_off = as_off + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      s16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rb = wn * 64 + i * 16 + fr;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[ks][i]) : "v"(ws_off + rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4)));
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ra = wm * 64 + i * 16 + fr;
-        a[i] = *(const s16x8*)(As + ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
-        const int rb = wn * 64 + i * 16 + fr;
-        b[i] = *(const s16x8*)(Ws + rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[ks][i]) : "v"(as_off + ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4)));
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(b[0][0]),
+                 "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]),
+                 "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
     cur = cur == 2 ? 0 : cur + 1;
   }
 #undef V2_STAGE
