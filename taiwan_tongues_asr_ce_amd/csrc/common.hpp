@@ -71,6 +71,8 @@ void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s);  // requires M%128
 bool gemm_bf16_fast_ok(const GemmArgs& g);
 void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s);
 bool gemm_bf16_v2_ok(const GemmArgs& g);
+void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s);
+bool gemm_bf16_v3_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);

@@ -320,6 +320,7 @@ void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
       const char* v = getenv("TTASR_GEMM");  // "v1": 128x128 two-stage kernel, default: 256x128 three-stage
+      if ((!v || v[1] == '3') && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->stream); return; }
       if (!(v && v[1] == '1') && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->stream); return; }
       if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->stream); return; }
     }

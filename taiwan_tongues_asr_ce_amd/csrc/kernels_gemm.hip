@@ -282,7 +282,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  // grouped raster: bands of GM m-tiles, n-tile fastest across the band, m-tile fastest inside it, so the ~32
+  // tiles an XCD runs at once form a 4 x 8 patch (4 A panels + 8 W panels ~ 5 MB against its 4 MiB L2)
+  // instead of 1 x 32 (measured: 34 % L2 misses with the row-major order = every W panel missed).
+  constexpr int GM = 4;
+  const int band = tile / (GM * tiles_n);
+  const int rows_in_band = min(GM, tiles_m - band * GM);
+  const int in_band = tile - band * GM * tiles_n;
+  const int tn = in_band / rows_in_band;
+  const int tm = band * GM + (in_band - tn * rows_in_band);
   const int m0 = tm * BM, n0 = tn * BN;
   const bf16_t* A = (const bf16_t*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
   const bf16_t* W = (const bf16_t*)g.W;
@@ -392,6 +400,139 @@ void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 128;
   hipLaunchKernelGGL(gemm_bf16_v2_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 3 * 49152, s, g, tiles_m, tiles_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_bf16_v3: 256x256x32 stages, FOUR-stage LDS ring (128 KiB), 8 waves as 2 (M) x 4 (N), 128x64 per wave.
+// The two wave groups (waves 0-3 / 4-7, i.e. the two SIMD partners) run staggered by one barrier: while
+// one group issues its LDS-DMA (4 x global_load_lds) and fragment reads (12 x ds_read_b128), its partner
+// on the same SIMD runs its 32 MFMAs, so the matrix pipe sees matrix-beside-memory instead of two waves
+// doing the same thing in lockstep (MI355X_MICROARCH "Two waves per SIMD", items 5 and 9).
+// Per iteration t and wave:   A_t: s_waitcnt vmcnt(4) [own pieces of stage t+1 landed]; s_barrier;
+//                                  issue stage t+3 -> slot (t+3)&3; read fragments of stage t; lgkmcnt(0)
+//                             B_t: s_barrier; 32 MFMAs
+// Group 1 executes one extra barrier before the loop and group 0 one after it, so group 0's A_t barrier
+// pairs with group 1's B_{t-1} barrier.  RAW: every wave has waited for its stage-t pieces one phase before
+// anyone reads stage t.  WAR: slot (t+3)&3 held stage t-1, whose fragment reads were drained (lgkmcnt(0))
+// before the barrier that precedes the first overwrite.
+// LDS image per operand stage: [256 rows][4 chunks of 16 B]; chunk c of row r sits in slot c ^ H((r>>2)&3),
+// H = {0,2,3,1}, which makes every ds_read_b128 lane group hit 16 distinct 16-byte bank slots.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int v3_h(int q) { return (0x78 >> (q * 2)) & 3; }  // {0,2,3,1} packed two bits each
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, BK = 32;
+  constexpr int OP_BYTES = BM * BK * 2, STAGE_BYTES = 2 * OP_BYTES;  // 16K + 16K
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GM = 4;
+  const int band = tile / (GM * tiles_n);
+  const int rows_in_band = min(GM, tiles_m - band * GM);
+  const int in_band = tile - band * GM * tiles_n;
+  const int tn = in_band / rows_in_band;
+  const int tm = band * GM + (in_band - tn * rows_in_band);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16_t* A = (const bf16_t*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
+  const bf16_t* W = (const bf16_t*)g.W;
+
+  // staging: one wave-instruction = 16 rows x 64 B; wave w moves rows (2w+p)*16 .. +15 of A and of W
+  const int srow = lane >> 2, sslot = lane & 3;
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (wave * 2 + p) * 16 + srow;
+    const int chunk = sslot ^ v3_h((row >> 2) & 3);
+    a_src[p] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+    w_src[p] = W + (int64_t)(n0 + row) * g.ldw + chunk * 8;
+  }
+#define V3_STAGE(slot_, k0_)                                                                   \
+  do {                                                                                         \
+    char* base_ = smem + (slot_) * STAGE_BYTES;                                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                            \
+      glds16(a_src[p] + (k0_), base_ + (wave * 2 + p) * 1024);                                 \
+      glds16(w_src[p] + (k0_), base_ + OP_BYTES + (wave * 2 + p) * 1024);                      \
+    }                                                                                          \
+  } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = g.K / BK;  // >= 4
+  V3_STAGE(0, 0);
+  V3_STAGE(1, BK);
+  V3_STAGE(2, 2 * BK);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // stages 0 and 1 landed (own pieces)
+  if (wm == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs one barrier behind
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // per-lane fragment offsets inside an operand stage (row r = base + 16*i + fr -> (r>>2)&3 == (fr>>2)&3)
+  const uint32_t frag_off = (uint32_t)(fr * 64 + ((fq ^ v3_h((fr >> 2) & 3)) << 4));
+  const uint32_t a_off = lds_base + wm * 128 * 64 + frag_off;
+  const uint32_t w_off = lds_base + OP_BYTES + wn * 64 * 64 + frag_off;
+
+  for (int t = 0; t < nt; ++t) {
+    // ---- phase A ----
+    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 3 < nt) V3_STAGE((t + 3) & 3, (t + 3) * BK);
+    s16x8 a[8], b[4];
+    const uint32_t so = (uint32_t)((t & 3) * STAGE_BYTES);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(w_off + so + j * 16 * 64));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(a_off + so + i * 16 * 64));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase B ----
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count
+#undef V3_STAGE
+  const int64_t zoff = (int64_t)blockIdx.z * g.epi.batch_stride_c;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + fr;
+    if (m < g.M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) epi_store4(g.epi, zoff, m, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+    }
+  }
+}
+
+bool gemm_bf16_v3_ok(const GemmArgs& g) {
+  return g.N % 256 == 0 && g.K % 32 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.epi.ldc % 4 == 0 &&
+         ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
+}
+void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    attr_done = true;
+  }
+  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+  hipLaunchKernelGGL(gemm_bf16_v3_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
 }
 
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
