@@ -108,15 +108,19 @@ template <> struct RowVec<bf16_t> {
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
 
+// Single pass, one memory round trip for pos <= 32*UNROLL cached keys: every lane keeps an online-softmax
+// state (m, l, acc[VEC]) for its row slot, K and V rows of an iteration are requested together, and the
+// 8 x 4 slots are merged once at the end (flash-decoding inside the workgroup).  With identity_pages the
+// page index is computed (b * pages_per_seq + t / 16) instead of loaded, which removes a dependent load.
 template <typename T>
 __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
                                                                const int32_t* __restrict__ page_table, int pages_per_seq,
-                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H) {
+                                                               int identity_pages, const int32_t* __restrict__ step,
+                                                               T* __restrict__ out, int H) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
-  __shared__ float sc[448 + 64];
   __shared__ float part[4][64];
-  __shared__ float red[8];
+  __shared__ float red[4][2];
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64, pos = *step;
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
@@ -126,94 +130,81 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
   RowVec<T>::load(qp + d + sub * VEC, kn);
   RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
   const int32_t* pt = page_table + b * pages_per_seq;
+  auto page_of = [&](int t) { return identity_pages ? b * pages_per_seq + t / PAGE : pt[t / PAGE]; };
   if (wave == 0 && rin == 0) {  // append this step's k, v
-    const int page = pt[pos / PAGE];
+    const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
     T* vdst = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (pos % PAGE)) * 64;
     *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
     *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
   }
-  // cached keys 0..pos-1: row t = (it*4 + wave)*RPI + rin; the new key/value come from registers
+  // this lane's slot: rows t = (it*4 + wave)*RPI + rin of the cached keys 0..pos-1
+  float m_run = -1e30f, l_run = 0.f, acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
   const int n_it = (pos + 4 * RPI - 1) / (4 * RPI);
-  float mloc = -1e30f;
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    float kv[UNROLL][VEC];
+    float kv[UNROLL][VEC], vv[UNROLL][VEC];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      const int tc = min(t, pos - 1);  // always load (clamped): no branch around the load, loads stay in flight together
-      const int page = pt[tc / PAGE];
-      RowVec<T>::load(pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (tc % PAGE)) * 64 + sub * VEC, kv[u]);
+      const int tc = min(((it0 + u) * 4 + wave) * RPI + rin, pos - 1);  // clamped, unconditional loads
+      const int64_t base = ((int64_t)page_of(tc) * 2 * H + h) * PAGE + (tc % PAGE);
+      RowVec<T>::load(pool + base * 64 + sub * VEC, kv[u]);
+      RowVec<T>::load(pool + (base + (int64_t)H * PAGE) * 64 + sub * VEC, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int t = ((it0 + u) * 4 + wave) * RPI + rin;
       float s = 0.f;
-      if (t < pos) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[u][j], s);
-      }
+      for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[u][j], s);
 #pragma unroll
       for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
       if (t < pos) {
-        if (sub == 0) sc[t] = s;
-        mloc = fmaxf(mloc, s);
+        const float mn = fmaxf(m_run, s);
+        const float sc = __expf(m_run - mn), p = __expf(s - mn);
+        l_run = l_run * sc + p;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(acc[j], sc, p * vv[u][j]);
+        m_run = mn;
       }
     }
   }
-  float snew = 0.f;
+  if (wave == 0 && rin == 0) {  // the new token, from registers
+    float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) snew = fmaf(q[j], kn[j], snew);
+    for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kn[j], s);
 #pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) snew += __shfl_xor(snew, o);
-  mloc = wave_max(mloc);
-  if (lane == 0) red[wave] = mloc;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), snew);
-  float lsum = 0.f;
-  for (int t = tid; t < pos; t += 256) {
-    float p = __expf(sc[t] - mx);
-    sc[t] = p;
-    lsum += p;
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    const float mn = fmaxf(m_run, s);
+    const float sc = __expf(m_run - mn), p = __expf(s - mn);
+    l_run = l_run * sc + p;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(acc[j], sc, p * vn[j]);
+    m_run = mn;
   }
-  lsum = wave_sum(lsum);
-  if (lane == 0) red[4 + wave] = lsum;
+  // merge the slots: workgroup max, then weights exp(m - M)
+  float mw = wave_max(m_run);
+  if (lane == 0) red[wave][0] = mw;
   __syncthreads();
-  const float pnew = __expf(snew - mx);
-  const float denom = (red[4] + red[5]) + (red[6] + red[7]) + pnew;
-  float acc[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = (wave == 0 && rin == 0) ? pnew * vn[j] : 0.f;
-  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    float vv[UNROLL][VEC];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      const int tc = min(t, pos - 1);
-      const int page = pt[tc / PAGE];
-      RowVec<T>::load(pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (tc % PAGE)) * 64 + sub * VEC, vv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      if (t < pos) {
-        const float p = sc[t];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vv[u][j], acc[j]);
-      }
-    }
-  }
+  const float M = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+  const float wgt = __expf(m_run - M);
+  float lw = (sub == 0) ? l_run * wgt : 0.f;  // l is replicated over the LPR lanes of a row slot: count it once
+  lw = wave_sum(lw);
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
+    acc[j] *= wgt;
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
   }
+  if (lane == 0) red[wave][1] = lw;
   if (rin == 0) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) part[wave][sub * VEC + j] = acc[j];
   }
   __syncthreads();
   if (tid < 64) {
+    const float denom = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     const float v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
   }
@@ -221,8 +212,9 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                              const int32_t* step, T* out, int B, int H, hipStream_t s) {
+  // the engine's page table is the identity map until beam search re-indexes it
   hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, step, out, H);
+                     pages_per_seq, 1, step, out, H);
 }
 template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, const int32_t*, float*, int,
                                              int, hipStream_t);

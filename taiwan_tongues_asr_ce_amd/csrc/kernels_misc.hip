@@ -152,14 +152,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (row >= rows) return;
   const float4* xr = (const float4*)(x + (int64_t)row * d);
   const int nv = d >> 2;
-  float4 v[NV];
-  float s = 0.f;
+  // every load of the kernel is issued up front (clamped, unconditional): x row, gamma, beta - one memory
+  // round trip in total; a load placed after the reductions costs a second one (~1 us in a decode chain)
+  float4 v[NV], gm[NV], bt[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int i = lane + 64 * j;
-    v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const int i = min(lane + 64 * j, nv - 1);
+    v[j] = xr[i];
+    gm[j] = ((const float4*)gamma)[i];
+    bt[j] = ((const float4*)beta)[i];
   }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (lane + 64 * j < nv) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
   const float mean = wave_sum(s) / d;
   float q = 0.f;
 #pragma unroll
@@ -175,15 +181,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int j = 0; j < NV; ++j) {
     const int i = lane + 64 * j;
     if (i < nv) {
-      float4 gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
-      float r0 = (v[j].x - mean) * rstd * gm.x + bt.x, r1 = (v[j].y - mean) * rstd * gm.y + bt.y;
-      float r2 = (v[j].z - mean) * rstd * gm.z + bt.z, r3 = (v[j].w - mean) * rstd * gm.w + bt.w;
+      float r0 = (v[j].x - mean) * rstd * gm[j].x + bt[j].x, r1 = (v[j].y - mean) * rstd * gm[j].y + bt[j].y;
+      float r2 = (v[j].z - mean) * rstd * gm[j].z + bt[j].z, r3 = (v[j].w - mean) * rstd * gm[j].w + bt[j].w;
       if constexpr (sizeof(T) == 4) {
         ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
       } else {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        bf2 lo = {(__bf16)r0, (__bf16)r1}, hi = {(__bf16)r2, (__bf16)r3};
         uint2 p;
-        p.x = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
-        p.y = (uint32_t)f2bf(r2) | ((uint32_t)f2bf(r3) << 16);
+        p.x = __builtin_bit_cast(uint32_t, lo);
+        p.y = __builtin_bit_cast(uint32_t, hi);
         ((uint2*)o)[i] = p;
       }
     }

@@ -43,16 +43,19 @@ void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, in
                      row_offset);
 }
 
-template <int NB>  // batch blocks of 16 rows
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
-                                                          int B, int N, int K, int ksplit, GemmEpi e) {
-  constexpr int U = 5;
-  __shared__ float red[4][NB][256];
+// Latency rule for every decode-step kernel (measured: one dependent memory round trip costs ~1.5 us in
+// the launch chain, a kernel boundary ~1.6 us): ALL loads of the kernel - weight fragments, batch rows,
+// bias, residual - are issued before the first use, so the kernel pays one round trip.
+template <int NB, int NW>  // NB batch blocks of 16 rows; NW waves per workgroup splitting K
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
+                                                              int B, int N, int K, int ksplit, GemmEpi e) {
+  constexpr int U = 10;  // k-steps in flight per wave (all of them for the Whisper shapes)
+  __shared__ float red[NW][NB][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
   const int kb_per = K / 32;
-  const int steps_per_wave = kb_per / (4 * ksplit);
-  const int kb0 = (ks * 4 + wave) * steps_per_wave;
+  const int steps_per_wave = kb_per / (NW * ksplit);
+  const int kb0 = (ks * NW + wave) * steps_per_wave;
   const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
   const bf16_t* xp[NB];
 #pragma unroll
@@ -60,30 +63,35 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
     int b = min(bb * 16 + (lane & 15), B - 1);
     xp[bb] = x + (int64_t)b * K + kb0 * 32 + 8 * (lane >> 4);
   }
+  // epilogue operands of this thread's (b, n) cells, requested now
+  const int en = min(nb * 16 + (tid & 15), N - 1);
+  float ebias = 0.f, eres[NB];
+  if (tid < 256) {
+    if (e.bias && (ksplit == 1 || ks == 0)) ebias = e.bias[en];
+#pragma unroll
+    for (int bb = 0; bb < NB; ++bb) {
+      const int b = min(bb * 16 + (tid >> 4), B - 1);
+      eres[bb] = (e.residual && ksplit == 1) ? e.residual[(int64_t)b * e.ldc + en] : 0.f;
+    }
+  }
   f32x4 acc[NB];
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int i = 0;
-  for (; i + U <= steps_per_wave; i += U) {
+  for (int i0 = 0; i0 < steps_per_wave; i0 += U) {
     u32x4 w[U], xv[U][NB];
 #pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (int64_t)(i + u) * 64);
+    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (int64_t)min(i0 + u, steps_per_wave - 1) * 64);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int bb = 0; bb < NB; ++bb) xv[u][bb] = *(const u32x4*)(xp[bb] + (i + u) * 32);
+      for (int bb = 0; bb < NB; ++bb) xv[u][bb] = *(const u32x4*)(xp[bb] + min(i0 + u, steps_per_wave - 1) * 32);
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u < steps_per_wave) {
 #pragma unroll
-      for (int bb = 0; bb < NB; ++bb)
-        acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u][bb], acc[bb], 0, 0, 0);
-  }
-  for (; i < steps_per_wave; ++i) {
-    u32x4 w = __builtin_nontemporal_load(wp + (int64_t)i * 64);
-#pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-      u32x4 xv = *(const u32x4*)(xp[bb] + i * 32);
-      acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w, *(s16x8*)&xv, acc[bb], 0, 0, 0);
+        for (int bb = 0; bb < NB; ++bb)
+          acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u][bb], acc[bb], 0, 0, 0);
+      }
     }
   }
   // D layout: col = lane & 15 = batch row, row = (lane >> 4) * 4 + r = output n.  LDS index = b * 16 + n.
@@ -92,22 +100,31 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][bb][(lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
   __syncthreads();
+  if (NW > 4 && tid >= 256) return;  // the first four waves finish the tile
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) {
-    float v = (red[0][bb][tid] + red[1][bb][tid]) + (red[2][bb][tid] + red[3][bb][tid]);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][bb][tid];
     const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
+    v += ebias;
     if (b < B && n < N) {
       if (ksplit > 1) {  // accumulate into the f32 residual stream
-        if (ks == 0 && e.bias) v += e.bias[n];
         atomicAdd(e.out_f32 + (int64_t)b * e.ldc + n, v);
       } else {
-        if (e.bias) v += e.bias[n];
         if (e.act == 1) v = gelu_erf(v);
         const int64_t idx = (int64_t)b * e.ldc + n;
-        if (e.residual) v += e.residual[idx];
+        v += eres[bb];
         if (e.out_f32) e.out_f32[idx] = v;
         if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
       }
+    }
+    if (e.stats_out) {  // (ksplit == 1) LN statistics of the finished residual rows: 16 columns per thread group
+      const bool ok = b < B && n < N;
+      float s1 = ok ? v : 0.f, s2 = ok ? v * v : 0.f;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if ((tid & 15) == 0 && b < B) { atomicAdd(e.stats_out + 2 * b, s1); atomicAdd(e.stats_out + 2 * b + 1, s2); }
     }
   }
 }
@@ -115,20 +132,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
 // Picks the K split: residual GEMMs (out_f32 == residual, no activation, no T output) may split K across
 // workgroups; the others keep ksplit = 1.  Returns false when the shape does not fit (caller falls back
 // to gemm_basic).
+template <int NB>
+static void launch_skinny_nw(int nw, dim3 grid, hipStream_t s, const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, int ksplit,
+                             const GemmEpi& e) {
+  if (nw == 16) hipLaunchKernelGGL((gemm_skinny_kernel<NB, 16>), grid, dim3(1024), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else if (nw == 8) hipLaunchKernelGGL((gemm_skinny_kernel<NB, 8>), grid, dim3(512), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<NB, 4>), grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+}
+
 bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s) {
   if (B < 1 || B > 64 || K % 128 != 0) return false;
   const int n_blocks = (N + 15) / 16;
   const int kb_per = K / 32;
-  int ksplit = 1;
+  int ksplit = 1, nw = 4;
   const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t && !e.rowtab;
-  if (can_split) {
+  if (e.stats_out) {
+    // the workgroup must finish whole rows (LN statistics): no K split across workgroups, so split K
+    // across up to 16 waves inside the workgroup instead
+    if (B <= 32 && kb_per % 16 == 0 && kb_per / 16 >= 4) nw = 16;
+    else if (kb_per % 8 == 0 && kb_per / 8 >= 3) nw = 8;
+  } else if (can_split) {
     while (n_blocks * ksplit < 512 && kb_per % (8 * ksplit) == 0 && kb_per / (8 * ksplit) >= 4) ksplit *= 2;
   }
-  if (kb_per % (4 * ksplit) != 0) return false;
+  if (kb_per % (nw * ksplit) != 0) return false;
   dim3 grid(n_blocks, ksplit);
-  if (B <= 16) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else if (B <= 32) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+  if (B <= 16) launch_skinny_nw<1>(nw, grid, s, Wsh, x, B, N, K, ksplit, e);
+  else if (B <= 32) launch_skinny_nw<2>(nw, grid, s, Wsh, x, B, N, K, ksplit, e);
+  else launch_skinny_nw<4>(4, grid, s, Wsh, x, B, N, K, ksplit, e);
   return true;
 }
 
@@ -258,5 +288,106 @@ bool launch_gemm_skinny_ln(const bf16_t* Wsh, const float* xf, const float* gamm
   dim3 grid((N + 15) / 16);
   if (NB == 1) hipLaunchKernelGGL(gemm_skinny_ln_kernel<1>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
   else hipLaunchKernelGGL(gemm_skinny_ln_kernel<2>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
+  return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm on the fly.  The residual GEMM that finishes a row block also accumulates sum(x), sum(x^2)
+// per row (GemmEpi::stats_out, two float atomics per row per workgroup), so the consumer needs no pass
+// over x: it loads its f32 x fragment, applies (x - mean) * rstd * gamma + beta in registers, rounds to
+// bf16 and feeds the MFMA.  This removes the three standalone LayerNorm launches per decoder layer
+// (each cost a launch boundary + a DRAM round trip, ~7 us in the profile) without the per-workgroup
+// re-normalisation of the LDS-staged variant above.  Variance = E[x^2] - mean^2 in f32.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256) void gemm_skinny_lnx_kernel(const bf16_t* __restrict__ Wsh, const float* __restrict__ xf,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int B, int N, int K, GemmEpi e) {
+  constexpr int U = 5;
+  __shared__ float red[4][NB][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.x;
+  const int kb_per = K / 32;
+  const int steps = kb_per / 4;
+  const int kb0 = wave * steps;
+  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
+  const int koff = kb0 * 32 + 8 * (lane >> 4);
+  const float* xp[NB];
+  float mean[NB], rstd[NB];
+  const float invK = 1.0f / K;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    const int b = min(bb * 16 + (lane & 15), B - 1);
+    xp[bb] = xf + (int64_t)b * K + koff;
+    const float s1 = stats[2 * b], s2 = stats[2 * b + 1];
+    mean[bb] = s1 * invK;
+    rstd[bb] = rsqrtf(fmaxf(s2 * invK - mean[bb] * mean[bb], 0.f) + 1e-5f);
+  }
+  const float* gp = gamma + koff;
+  const float* bp = beta + koff;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i0 = 0; i0 < steps; i0 += U) {
+    u32x4 w[U];
+    float4 xv[U][NB][2], gv[U][2], bv[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u, steps - 1);  // clamped: loads are unconditional, the MFMA is skipped past the end
+      w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64);
+      gv[u][0] = *(const float4*)(gp + i * 32); gv[u][1] = *(const float4*)(gp + i * 32 + 4);
+      bv[u][0] = *(const float4*)(bp + i * 32); bv[u][1] = *(const float4*)(bp + i * 32 + 4);
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        xv[u][bb][0] = *(const float4*)(xp[bb] + i * 32);
+        xv[u][bb][1] = *(const float4*)(xp[bb] + i * 32 + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u < steps) {
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          // LN(x) = x * (rstd * gamma) + (beta - mean * rstd * gamma); hardware bf16 pack (v_cvt_pk_bf16_f32)
+          const float r = rstd[bb], mr = -mean[bb] * rstd[bb];
+          const float4 x0 = xv[u][bb][0], x1 = xv[u][bb][1];
+          const float4 g0 = gv[u][0], g1 = gv[u][1], c0 = bv[u][0], c1 = bv[u][1];
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          u32x4 xb;
+          { bf2 t = {(__bf16)fmaf(fmaf(x0.x, r, mr), g0.x, c0.x), (__bf16)fmaf(fmaf(x0.y, r, mr), g0.y, c0.y)}; xb[0] = __builtin_bit_cast(uint32_t, t); }
+          { bf2 t = {(__bf16)fmaf(fmaf(x0.z, r, mr), g0.z, c0.z), (__bf16)fmaf(fmaf(x0.w, r, mr), g0.w, c0.w)}; xb[1] = __builtin_bit_cast(uint32_t, t); }
+          { bf2 t = {(__bf16)fmaf(fmaf(x1.x, r, mr), g1.x, c1.x), (__bf16)fmaf(fmaf(x1.y, r, mr), g1.y, c1.y)}; xb[2] = __builtin_bit_cast(uint32_t, t); }
+          { bf2 t = {(__bf16)fmaf(fmaf(x1.z, r, mr), g1.z, c1.z), (__bf16)fmaf(fmaf(x1.w, r, mr), g1.w, c1.w)}; xb[3] = __builtin_bit_cast(uint32_t, t); }
+          acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xb, acc[bb], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][bb][(lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
+  __syncthreads();
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+    float v = (red[0][bb][tid] + red[1][bb][tid]) + (red[2][bb][tid] + red[3][bb][tid]);
+    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
+    if (b < B && n < N) {
+      if (e.bias) v += e.bias[n];
+      if (e.act == 1) v = gelu_erf(v);
+      const int64_t idx = (int64_t)b * e.ldc + n;
+      if (e.out_f32) e.out_f32[idx] = v;
+      if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
+    }
+  }
+}
+
+bool launch_gemm_skinny_lnx(const bf16_t* Wsh, const float* xf, const float* stats_in, const float* gamma, const float* beta,
+                            int B, int N, int K, const GemmEpi& e, hipStream_t s) {
+  if (B < 1 || B > 32 || K % 128 != 0 || e.residual || e.rowtab || e.stats_out) return false;
+  dim3 grid((N + 15) / 16);
+  if (B <= 16) hipLaunchKernelGGL(gemm_skinny_lnx_kernel<1>, grid, dim3(256), 0, s, Wsh, xf, stats_in, gamma, beta, B, N, K, e);
+  else hipLaunchKernelGGL(gemm_skinny_lnx_kernel<2>, grid, dim3(256), 0, s, Wsh, xf, stats_in, gamma, beta, B, N, K, e);
   return true;
 }
