@@ -53,7 +53,6 @@ struct GemmEpi {
   int headsplit = 0;                // 1: out_t index = which*hs_which + ((b*H+h)*T + t)*64 + j
   int hs_T = 0, hs_H = 0, hs_d = 0;
   int64_t hs_which = 0;
-  float* stats_out = nullptr;       // [M][2]: decode GEMMs add sum(v), sum(v*v) of the rows they finish (LN statistics)
 };
 
 struct GemmArgs {
@@ -81,12 +80,6 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, T* 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
 void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s);
 bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s);
-// LayerNorm applied on the fly from row statistics produced by the previous residual GEMM
-bool launch_gemm_skinny_lnx(const bf16_t* Wsh, const float* xf, const float* stats_in, const float* gamma, const float* beta,
-                            int B, int N, int K, const GemmEpi& e, hipStream_t s);
-bool launch_gemm_skinny_ln(const bf16_t* Wsh, const float* xf, const float* gamma, const float* beta, int B, int N, int K,
-                           const GemmEpi& e, hipStream_t s);
-
 // mel
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
                 const float* filters /*[201][n_mels]*/, const float* dft_cos, const float* dft_sin /*[400]*/,
@@ -124,8 +117,7 @@ struct RuleParams {
   int eot, no_timestamps, timestamp_begin, no_speech, sot_index, timestamps, max_initial, suppress_eot;
 };
 template <typename T>
-void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, float* stats /*[B][2] or null*/,
-                  int B, int d, hipStream_t s);
+void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
 template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
                              int64_t pool_layer_off, const int32_t* step, T* out /*[B][d]*/, int B, int H, hipStream_t s);

@@ -48,7 +48,6 @@ struct ttasr_ctx {
   bool finalized = false;
   bool force_basic = false;
   bool use_graph = true;
-  bool no_ln_fuse = false;
   size_t esz = 4;  // sizeof(T)
   int T = 0, F = 0, d = 0, H = 0, ffn = 0, V = 0, ldv = 0, M = 0, maxB = 0, n_samples = 0;
   int pages_per_seq = 0;
@@ -75,8 +74,6 @@ struct ttasr_ctx {
   void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
   float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
   float* rows_out = nullptr;
-  float* ln_stats = nullptr;  // [3*L + 1][maxB][2] row statistics for LN-on-the-fly (bf16 decode)
-  bool ln_stats_mode = false;
   int skip_mask = 0;  // TTASR_SKIP: timing experiments only (1 LN, 2 decode GEMMs, 4 self-attn, 8 cross-attn, 16 select)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
@@ -231,7 +228,7 @@ int build_weights(ttasr_ctx* c) {
   TRY(ln("model.decoder.layer_norm", &c->dlnf_g, &c->dlnf_b));
   if (c->bf16) {  // fragment-packed copies of every matrix the decode step streams
     auto packed = [&](const std::string& name, void** base, int64_t rows_total, int64_t K, int row_off) -> int {
-      if (!*base) TRY(alloc_mat(c, base, (rows_total + 15) / 16 * 16 * K));
+      if (!*base) TRY(alloc_mat(c, base, (rows_total + 31) / 32 * 32 * K));
       Slot& s = c->slots[name];
       s.sh_base = *base; s.sh_row_off = row_off;
       return 0;
@@ -289,7 +286,6 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(alloc_mat(c, &c->datt, B * d));
   TRY(alloc_mat(c, &c->dmid, B * c->ffn));
   TRY(dalloc(c, &c->logits, (size_t)B * c->ldv * 4));
-  TRY(dalloc(c, &c->ln_stats, (size_t)(3 * c->cfg.dec_layers + 1) * B * 2 * 4));
   c->max_new_alloc = c->cfg.n_text_ctx;
   c->max_prompt_alloc = c->cfg.n_text_ctx;
   TRY(dalloc(c, &c->st.cur_tok, B * 4)); TRY(dalloc(c, &c->st.step, 16)); TRY(dalloc(c, &c->st.n_sampled, B * 4));
@@ -342,16 +338,9 @@ void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
   launch_gemm_basic<T>(g, c->stream);
 }
 
-// LayerNorm(x) followed by a decode GEMM.  bf16: one launch, LN applied on the fly from the row statistics in
-// `stats` (written by the embed kernel / the previous residual GEMM); otherwise LN kernel + GEMM.
+// LayerNorm(x) followed by a decode GEMM (two launches: fusing LN into the GEMM was measured slower)
 template <typename T>
-void dec_ln_gemm(ttasr_ctx* c, const float* g_, const float* b_, const float* stats, int B, const GemmArgs& g, const void* Wsh) {
-  if constexpr (sizeof(T) == 2) {
-    if (c->ln_stats_mode && Wsh && stats &&
-        launch_gemm_skinny_lnx((const bf16_t*)Wsh, c->dx, stats, g_, b_, B, g.N, g.K, g.epi, c->stream)) return;
-    if (!c->force_basic && !c->no_ln_fuse && Wsh &&
-        launch_gemm_skinny_ln((const bf16_t*)Wsh, c->dx, g_, b_, B, g.N, g.K, g.epi, c->stream)) return;
-  }
+void dec_ln_gemm(ttasr_ctx* c, const float* g_, const float* b_, int B, const GemmArgs& g, const void* Wsh) {
   if (!(c->skip_mask & 1)) launch_layernorm<T>(c->dx, g_, b_, (T*)c->dh, B, c->d, c->stream);
   dec_gemm<T>(c, g, Wsh);
 }
@@ -421,35 +410,27 @@ template <typename T>
 void run_decode_step(ttasr_ctx* c, int B, int mode) {
   const int d = c->d, ffn = c->ffn;
   hipStream_t s = c->stream;
-  const bool lnx = sizeof(T) == 2 && c->ln_stats_mode;
-  const size_t slot = (size_t)c->maxB * 2;  // floats per statistics slot
-  auto st_in = [&](int i) -> const float* { return lnx ? c->ln_stats + i * slot : nullptr; };
-  auto st_out = [&](int i) -> float* { return lnx ? c->ln_stats + i * slot : nullptr; };
-  if (lnx) hipMemsetAsync(c->ln_stats, 0, (size_t)(3 * c->cfg.dec_layers + 1) * slot * 4, s);
-  launch_embed<T>(c->st.cur_tok, c->st.step, (const T*)c->emb, (const T*)c->dpos, c->dx, st_out(0), B, d, s);
+  launch_embed<T>(c->st.cur_tok, c->st.step, (const T*)c->emb, (const T*)c->dpos, c->dx, B, d, s);
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
     { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv;
-      dec_ln_gemm<T>(c, L.ln1g, L.ln1b, st_in(3 * l), B, g, L.wqkv_sh); }
+      dec_ln_gemm<T>(c, L.ln1g, L.ln1b, B, g, L.wqkv_sh); }
     if (!(c->skip_mask & 4)) launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
                                (int64_t)l * c->pool_layer_elems, c->st.step, (T*)c->datt, B, c->H, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx;
-      g.epi.stats_out = st_out(3 * l + 1); dec_gemm<T>(c, g, L.wo_sh); }
+    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wo_sh); }
     { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq;
-      dec_ln_gemm<T>(c, L.ln2g, L.ln2b, st_in(3 * l + 1), B, g, L.wqx_sh); }
+      dec_ln_gemm<T>(c, L.ln2g, L.ln2b, B, g, L.wqx_sh); }
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
     if (!(c->skip_mask & 8)) launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx;
-      g.epi.stats_out = st_out(3 * l + 2); dec_gemm<T>(c, g, L.wox_sh); }
+    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wox_sh); }
     { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      dec_ln_gemm<T>(c, L.ln3g, L.ln3b, st_in(3 * l + 2), B, g, L.w1_sh); }
-    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx;
-      g.epi.stats_out = st_out(3 * l + 3); dec_gemm<T>(c, g, L.w2_sh); }
+      dec_ln_gemm<T>(c, L.ln3g, L.ln3b, B, g, L.w1_sh); }
+    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.w2_sh); }
   }
   if (mode != 2) {
     GemmArgs g = lin_args<T>(c->dh, c->emb, B, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
     g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-    dec_ln_gemm<T>(c, c->dlnf_g, c->dlnf_b, nullptr /* 3242 workgroups: one LN launch is cheaper */, B, g, c->emb_sh);
+    dec_ln_gemm<T>(c, c->dlnf_g, c->dlnf_b, B, g, c->emb_sh);
   }
   if (mode != 1 && !(c->skip_mask & 16)) launch_select(c->logits, c->st, c->rp, B, nullptr, s);
   launch_advance(c->st.step, s);
@@ -563,8 +544,6 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->n_samples = c->F * 160;
   c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
-  c->no_ln_fuse = getenv("TTASR_LN_FUSE") == nullptr;  // fused LN+GEMM measured slower (r1: +1 ms/step); opt-in
-  c->ln_stats_mode = c->bf16 && !c->force_basic && cfg->max_batch <= 32 && cfg->d_model % 128 == 0 && getenv("TTASR_LN_STATS") != nullptr;
   if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };

@@ -9,34 +9,18 @@
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ step,
                                                     const T* __restrict__ emb, const T* __restrict__ pos, float* __restrict__ x,
-                                                    float* __restrict__ stats, int d) {
-  __shared__ float red[8];
+                                                    int d) {
   const int b = blockIdx.x, p = *step;
   const T* e = emb + (int64_t)tok[b] * d;
   const T* pe = pos + (int64_t)p * d;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < d; i += 256) {
-    const float v = to_f<T>(e[i]) + to_f<T>(pe[i]);
-    x[(int64_t)b * d + i] = v;
-    s1 += v; s2 += v * v;
-  }
-  if (stats) {  // row statistics for the first LayerNorm of layer 0 (consumed by the LN-on-the-fly GEMM)
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      stats[2 * b] = (red[0] + red[1]) + (red[2] + red[3]);
-      stats[2 * b + 1] = (red[4] + red[5]) + (red[6] + red[7]);
-    }
-  }
+  for (int i = threadIdx.x; i < d; i += 256) x[(int64_t)b * d + i] = to_f<T>(e[i]) + to_f<T>(pe[i]);
 }
 template <typename T>
-void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, float* stats, int B, int d,
-                  hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, s, tok, step, emb, pos, x, stats, d);
+void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, s, tok, step, emb, pos, x, d);
 }
-template void launch_embed<float>(const int32_t*, const int32_t*, const float*, const float*, float*, float*, int, int, hipStream_t);
-template void launch_embed<bf16_t>(const int32_t*, const int32_t*, const bf16_t*, const bf16_t*, float*, float*, int, int, hipStream_t);
+template void launch_embed<float>(const int32_t*, const int32_t*, const float*, const float*, float*, int, int, hipStream_t);
+template void launch_embed<bf16_t>(const int32_t*, const int32_t*, const bf16_t*, const bf16_t*, float*, int, int, hipStream_t);
 
 __global__ void advance_kernel(int32_t* step) { *step += 1; }
 void launch_advance(int32_t* step, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step); }

@@ -1,393 +1,142 @@
-// Decode-time weight-streaming GEMM (bf16): out[b][n] = sum_k x[b][k] * W[n][k] for a handful of rows
-// b <= 64 (one row per sequence in the batch).  HBM-bound on the weights: every weight byte is read once
-// per step for the whole batch (SURVEY.md section 8d "algorithmic bytes per decode step").
+// Decode-time weight-streaming GEMM (bf16): out[b][n] = sum_k x[b][k] * W[n][k] for B <= 32 rows (one row per
+// sequence in the batch).  HBM-bound on the weights: every weight byte is read once per step for the whole
+// batch (SURVEY.md section 8d "algorithmic bytes per decode step").
 //
-// MI355X-native layout: the decoder weights are re-packed ONCE at load time into MFMA-fragment order so
-// the stream is perfectly coalesced with no LDS staging ("GEMV / M <= 16 decode weights: load straight to
-// VGPRs", cdna_hip_programming.md section 5): for n-block nb (16 output rows) and k-block kb (32 inputs)
-// the 1 KiB at ((nb * K/32 + kb) * 64 + lane) * 16 B holds W[nb*16 + (lane & 15)][kb*32 + 8*(lane >> 4) ..+8],
-// i.e. exactly lane `lane`'s A operand of v_mfma_f32_16x16x32_bf16.  The batch rows are the B operand
-// (x[b = lane & 15][k...], L2-resident), so D = W_tile * x^T with rows = n, cols = b.
-// Workgroup = 4 waves that split this block's K range; partial tiles are summed through LDS.  For the
-// residual GEMMs (out-proj, fc2) a second grid dimension splits K further and the partials are added to
-// the f32 residual stream with global float atomics (x += W h + b is an accumulation already).
+// MI355X-native layout: the decoder weights are re-packed ONCE at load time into MFMA-fragment order so the
+// stream is perfectly coalesced with no LDS staging ("GEMV / M <= 16 decode weights: load straight to VGPRs",
+// cdna_hip_programming.md section 5): for n-block nb (32 output rows) and k-step ks (16 inputs) the 1 KiB at
+// ((nb * K/16 + ks) * 64 + lane) * 16 B holds W[nb*32 + (lane & 31)][ks*16 + 8*(lane >> 5) ..+8], i.e. exactly
+// lane `lane`'s A operand of v_mfma_f32_32x32x16_bf16.  The batch rows are the B operand
+// (x[b = lane & 31][k...], L2-resident), so D = W_tile * x^T with rows = n, cols = b.
+//
+// What the measurements said (scratch/skinny_var.hip, fc1 shape, graph-replayed chain, boundary = 1.6 us):
+//   weight stream alone 3.5 us; + MFMA/LDS-reduce/store 4.6-4.8 us; + batch-row loads at a 1:1 byte ratio
+//   5.0 us, at the 2:1 ratio of the 16x16x32 form 7.1 us; nontemporal weight loads +1.8 us.
+// Hence: 32x32x16 (1 KiB of x per 1 KiB of W), plain loads, and every load of the kernel (fragments, bias,
+// residual) issued before the first use: one memory round trip per kernel (each extra one costs ~1.5 us in
+// the decode chain).  NW waves split K inside the workgroup (LDS reduce); residual GEMMs additionally split K
+// across workgroups and add their partials to the f32 residual stream with float atomics.
 #include "common.hpp"
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-__global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K,
-                                    int row_offset) {
-  // one thread per 16-byte output chunk
-  const int64_t n_chunks = (int64_t)rows * K / 8;
+__global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int row_offset) {
+  // one thread per 16-byte output chunk; rows past `rows` (padding of the last 32-row block) are left zero
+  const int ks_per = K / 16;
+  const int n_blocks = (rows + 31) / 32;
+  const int64_t n_chunks = (int64_t)n_blocks * ks_per * 64;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
-    const int kb_per = K / 32;
-    int lane = (int)(c & 63);
-    int64_t blk = c >> 6;
-    int kb = (int)(blk % kb_per);
-    int nb = (int)(blk / kb_per);
-    int r = nb * 16 + (lane & 15);
-    int k = kb * 32 + 8 * (lane >> 4);
-    const float* s = src + (int64_t)r * K + k;
+    const int lane = (int)(c & 63);
+    const int64_t blk = c >> 6;
+    const int ks = (int)(blk % ks_per), nb = (int)(blk / ks_per);
+    const int r = nb * 32 + (lane & 31);
+    if (r >= rows) continue;
+    const float* s = src + (int64_t)r * K + ks * 16 + 8 * (lane >> 5);
     uint4 o;
     o.x = (uint32_t)f2bf(s[0]) | ((uint32_t)f2bf(s[1]) << 16);
     o.y = (uint32_t)f2bf(s[2]) | ((uint32_t)f2bf(s[3]) << 16);
     o.z = (uint32_t)f2bf(s[4]) | ((uint32_t)f2bf(s[5]) << 16);
     o.w = (uint32_t)f2bf(s[6]) | ((uint32_t)f2bf(s[7]) << 16);
-    int64_t dst_blk = ((int64_t)(nb + row_offset / 16) * kb_per + kb) * 64 + lane;
-    ((uint4*)dst)[dst_blk] = o;
+    ((uint4*)dst)[((int64_t)(nb + row_offset / 32) * ks_per + ks) * 64 + lane] = o;
   }
 }
 void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s) {
-  int64_t n_chunks = (int64_t)rows * K / 8;
-  int64_t nb = (n_chunks + 255) / 256;
+  const int64_t n_chunks = (int64_t)((rows + 31) / 32) * (K / 16) * 64;
+  const int64_t nb = (n_chunks + 255) / 256;
   hipLaunchKernelGGL(shuffle_cast_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, dst_base, rows, K,
                      row_offset);
 }
 
-// Latency rule for every decode-step kernel (measured: one dependent memory round trip costs ~1.5 us in
-// the launch chain, a kernel boundary ~1.6 us): ALL loads of the kernel - weight fragments, batch rows,
-// bias, residual - are issued before the first use, so the kernel pays one round trip.
-template <int NB, int NW>  // NB batch blocks of 16 rows; NW waves per workgroup splitting K
+template <int NW>  // NW waves per workgroup, each owning steps_per_wave k-steps of 16
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
                                                               int B, int N, int K, int ksplit, GemmEpi e) {
   constexpr int U = 10;  // k-steps in flight per wave (all of them for the Whisper shapes)
-  __shared__ float red[NW][NB][256];
+  __shared__ __attribute__((aligned(16))) float red[NW][32 * 32];  // [wave][b*32 + n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
-  const int kb_per = K / 32;
-  const int steps_per_wave = kb_per / (NW * ksplit);
-  const int kb0 = (ks * NW + wave) * steps_per_wave;
-  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
-  const bf16_t* xp[NB];
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-    int b = min(bb * 16 + (lane & 15), B - 1);
-    xp[bb] = x + (int64_t)b * K + kb0 * 32 + 8 * (lane >> 4);
+  const int ks_per = K / 16;
+  const int steps = ks_per / (NW * ksplit);
+  const int k0 = (ks * NW + wave) * steps;
+  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * ks_per + k0) * 64 + lane;
+  const bf16_t* xp = x + (int64_t)min(lane & 31, B - 1) * K + k0 * 16 + 8 * (lane >> 5);
+  // epilogue operands of this thread's 4 cells (b = tid>>3, n = nb*32 + 4*(tid&7) ..+3), requested now
+  const int eb = min(tid >> 3, B - 1), en = nb * 32 + 4 * (tid & 7);
+  float4 ebias = make_float4(0.f, 0.f, 0.f, 0.f), eres = ebias;
+  if (tid < 256 && en + 3 < N) {
+    if (e.bias && (ksplit == 1 || ks == 0)) ebias = *(const float4*)(e.bias + en);
+    if (e.residual && ksplit == 1) eres = *(const float4*)(e.residual + (int64_t)eb * e.ldc + en);
   }
-  // epilogue operands of this thread's (b, n) cells, requested now
-  const int en = min(nb * 16 + (tid & 15), N - 1);
-  float ebias = 0.f, eres[NB];
-  if (tid < 256) {
-    if (e.bias && (ksplit == 1 || ks == 0)) ebias = e.bias[en];
+  f32x16 acc;
 #pragma unroll
-    for (int bb = 0; bb < NB; ++bb) {
-      const int b = min(bb * 16 + (tid >> 4), B - 1);
-      eres[bb] = (e.residual && ksplit == 1) ? e.residual[(int64_t)b * e.ldc + en] : 0.f;
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int i0 = 0; i0 < steps; i0 += U) {
+    u32x4 w[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(i0 + u, steps - 1);  // clamped and unconditional: nothing branches around a load
+      w[u] = wp[(int64_t)i * 64];
+      xv[u] = *(const u32x4*)(xp + i * 16);
     }
-  }
-  f32x4 acc[NB];
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i0 = 0; i0 < steps_per_wave; i0 += U) {
-    u32x4 w[U], xv[U][NB];
-#pragma unroll
-    for (int u = 0; u < U; ++u) w[u] = __builtin_nontemporal_load(wp + (int64_t)min(i0 + u, steps_per_wave - 1) * 64);
 #pragma unroll
     for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) xv[u][bb] = *(const u32x4*)(xp[bb] + min(i0 + u, steps_per_wave - 1) * 32);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i0 + u < steps_per_wave) {
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb)
-          acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u][bb], acc[bb], 0, 0, 0);
-      }
-    }
+      if (i0 + u < steps) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u], acc, 0, 0, 0);
   }
-  // D layout: col = lane & 15 = batch row, row = (lane >> 4) * 4 + r = output n.  LDS index = b * 16 + n.
+  // D: col = lane & 31 = batch row b, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output n
 #pragma unroll
-  for (int bb = 0; bb < NB; ++bb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][bb][(lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
+  for (int g = 0; g < 4; ++g)
+    *(float4*)&red[wave][(lane & 31) * 32 + 8 * g + 4 * (lane >> 5)] =
+        make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
   __syncthreads();
-  if (NW > 4 && tid >= 256) return;  // the first four waves finish the tile
+  if (tid >= 256) return;
+  float4 v = *(const float4*)&red[0][(tid >> 3) * 32 + 4 * (tid & 7)];
 #pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-    float v = 0.f;
+  for (int w = 1; w < NW; ++w) {
+    const float4 t = *(const float4*)&red[w][(tid >> 3) * 32 + 4 * (tid & 7)];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  v.x += ebias.x; v.y += ebias.y; v.z += ebias.z; v.w += ebias.w;
+  const int b = tid >> 3;
+  if (b >= B) return;
+  float vv[4] = {v.x, v.y, v.z, v.w};
+  const float rr[4] = {eres.x, eres.y, eres.z, eres.w};
 #pragma unroll
-    for (int w = 0; w < NW; ++w) v += red[w][bb][tid];
-    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
-    v += ebias;
-    if (b < B && n < N) {
-      if (ksplit > 1) {  // accumulate into the f32 residual stream
-        atomicAdd(e.out_f32 + (int64_t)b * e.ldc + n, v);
+  for (int j = 0; j < 4; ++j) {
+    const int n = en + j;
+    if (n < N) {
+      const int64_t idx = (int64_t)b * e.ldc + n;
+      if (ksplit > 1) {
+        atomicAdd(e.out_f32 + idx, vv[j]);  // accumulate into the f32 residual stream
       } else {
-        if (e.act == 1) v = gelu_erf(v);
-        const int64_t idx = (int64_t)b * e.ldc + n;
-        v += eres[bb];
-        if (e.out_f32) e.out_f32[idx] = v;
-        if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
+        float o = vv[j];
+        if (en + 3 >= N && e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
+        if (e.act == 1) o = gelu_erf(o);
+        if (e.residual) o += (en + 3 < N) ? rr[j] : e.residual[idx];
+        if (e.out_f32) e.out_f32[idx] = o;
+        if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(o);
       }
-    }
-    if (e.stats_out) {  // (ksplit == 1) LN statistics of the finished residual rows: 16 columns per thread group
-      const bool ok = b < B && n < N;
-      float s1 = ok ? v : 0.f, s2 = ok ? v * v : 0.f;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      if ((tid & 15) == 0 && b < B) { atomicAdd(e.stats_out + 2 * b, s1); atomicAdd(e.stats_out + 2 * b + 1, s2); }
     }
   }
 }
 
-// Picks the K split: residual GEMMs (out_f32 == residual, no activation, no T output) may split K across
-// workgroups; the others keep ksplit = 1.  Returns false when the shape does not fit (caller falls back
-// to gemm_basic).
-template <int NB>
-static void launch_skinny_nw(int nw, dim3 grid, hipStream_t s, const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, int ksplit,
-                             const GemmEpi& e) {
-  if (nw == 16) hipLaunchKernelGGL((gemm_skinny_kernel<NB, 16>), grid, dim3(1024), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else if (nw == 8) hipLaunchKernelGGL((gemm_skinny_kernel<NB, 8>), grid, dim3(512), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<NB, 4>), grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
-}
-
+// Chooses (waves per workgroup, K split across workgroups) so that each wave owns <= 10 k-steps (one round
+// trip) and the grid has a few hundred workgroups.  Only residual GEMMs (x += W h + b) may split K across
+// workgroups.  Returns false when the shape does not fit (caller falls back to gemm_basic).
 bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s) {
-  if (B < 1 || B > 64 || K % 128 != 0) return false;
-  const int n_blocks = (N + 15) / 16;
-  const int kb_per = K / 32;
-  int ksplit = 1, nw = 4;
-  const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t && !e.rowtab;
-  if (e.stats_out) {
-    // the workgroup must finish whole rows (LN statistics): no K split across workgroups, so split K
-    // across up to 16 waves inside the workgroup instead
-    if (B <= 32 && kb_per % 16 == 0 && kb_per / 16 >= 4) nw = 16;
-    else if (kb_per % 8 == 0 && kb_per / 8 >= 3) nw = 8;
-  } else if (can_split) {
-    while (n_blocks * ksplit < 512 && kb_per % (8 * ksplit) == 0 && kb_per / (8 * ksplit) >= 4) ksplit *= 2;
+  if (B < 1 || B > 32 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
+  const int n_blocks = (N + 31) / 32;
+  const int ks_per = K / 16;
+  const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t;
+  int nw = 4, ksplit = 1;
+  if (can_split) {
+    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 5 && n_blocks * ksplit < 256) ksplit *= 2;
+    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 10) ksplit *= 2;
+  } else {
+    while (nw < 16 && ks_per % (nw * 2) == 0 && ks_per / nw > 10) nw *= 2;
+    if (nw < 8 && ks_per % 8 == 0 && ks_per / 8 >= 5 && n_blocks < 256) nw = 8;
   }
-  if (kb_per % (nw * ksplit) != 0) return false;
+  if (ks_per % (nw * ksplit) != 0) return false;
   dim3 grid(n_blocks, ksplit);
-  if (B <= 16) launch_skinny_nw<1>(nw, grid, s, Wsh, x, B, N, K, ksplit, e);
-  else if (B <= 32) launch_skinny_nw<2>(nw, grid, s, Wsh, x, B, N, K, ksplit, e);
-  else launch_skinny_nw<4>(4, grid, s, Wsh, x, B, N, K, ksplit, e);
-  return true;
-}
-
-// ------------------------------------------------------------------------------------------------
-// LayerNorm fused into the skinny GEMM: out = act(LN(x) W^T + b).  Every decode-step kernel costs one
-// dependent memory round trip plus a launch boundary whatever its size (a 1-thread kernel measures 4 us
-// under rocprofv3), so the 3 LayerNorms per decoder layer are folded into the GEMM that consumes them.
-// Each workgroup normalises all B rows itself (x is B*K*4 <= 160 KB, L2-resident; every wave owns whole
-// rows, so the statistics are wave-local: mean, then two-pass variance from registers, as the oracle) and
-// keeps the bf16 image [B][K] in LDS as the MFMA B operand.  The wave's weight fragments are requested
-// BEFORE the prologue, so their HBM latency hides behind it.
-// ------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(256) void gemm_skinny_ln_kernel(const bf16_t* __restrict__ Wsh, const float* __restrict__ xf,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int B, int N, int K, GemmEpi e) {
-  constexpr int MAXS = 10, NV = 5, ROWS = NB * 16, RPW = ROWS / 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int stride = K * 2 + 16;  // bytes per x row in LDS (+16: spreads the 16 rows of a fragment over the banks)
-  float* red = (float*)(smem + ROWS * stride);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = blockIdx.x;
-  const int kb_per = K / 32;
-  const int steps = kb_per / 4;  // per wave
-  const int kb0 = wave * steps;
-  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
-  u32x4 w[MAXS];
-#pragma unroll
-  for (int i = 0; i < MAXS; ++i) w[i] = __builtin_nontemporal_load(wp + (int64_t)min(i, steps - 1) * 64);
-
-  // ---- prologue: LayerNorm of the rows this wave owns -> bf16 LDS image ----
-  const int nv = K >> 2;
-  float4 gm[NV], bt[NV];
-#pragma unroll
-  for (int j = 0; j < NV; ++j) {
-    const int i = min(lane + 64 * j, nv - 1);
-    gm[j] = ((const float4*)gamma)[i];
-    bt[j] = ((const float4*)beta)[i];
-  }
-#pragma unroll
-  for (int r0 = 0; r0 < RPW; r0 += 4) {
-    float4 v[4][NV];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = min(wave * RPW + r0 + rr, B - 1);
-      const float4* xr = (const float4*)(xf + (int64_t)row * K);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) v[rr][j] = xr[min(lane + 64 * j, nv - 1)];
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < NV; ++j)
-        if (lane + 64 * j < nv) s += (v[rr][j].x + v[rr][j].y) + (v[rr][j].z + v[rr][j].w);
-      const float mean = wave_sum(s) / K;
-      float q = 0.f;
-#pragma unroll
-      for (int j = 0; j < NV; ++j)
-        if (lane + 64 * j < nv) {
-          float a = v[rr][j].x - mean, b2 = v[rr][j].y - mean, c = v[rr][j].z - mean, d2 = v[rr][j].w - mean;
-          q += (a * a + b2 * b2) + (c * c + d2 * d2);
-        }
-      const float rstd = rsqrtf(wave_sum(q) / K + 1e-5f);
-      char* dst = smem + (wave * RPW + r0 + rr) * stride;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nv) {
-          float y0 = (v[rr][j].x - mean) * rstd * gm[j].x + bt[j].x, y1 = (v[rr][j].y - mean) * rstd * gm[j].y + bt[j].y;
-          float y2 = (v[rr][j].z - mean) * rstd * gm[j].z + bt[j].z, y3 = (v[rr][j].w - mean) * rstd * gm[j].w + bt[j].w;
-          uint2 p;
-          p.x = (uint32_t)f2bf(y0) | ((uint32_t)f2bf(y1) << 16);
-          p.y = (uint32_t)f2bf(y2) | ((uint32_t)f2bf(y3) << 16);
-          *(uint2*)(dst + i * 8) = p;
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- main: D[n][b] += W_frag * x_frag ----
-  f32x4 acc[NB];
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    if (i < steps) {
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) {
-        const s16x8 xv = *(const s16x8*)(smem + (bb * 16 + (lane & 15)) * stride + (kb0 + i) * 64 + (lane >> 4) * 16);
-        acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[i], xv, acc[bb], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * NB + bb) * 256 + (lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
-  __syncthreads();
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-    float v = (red[(0 * NB + bb) * 256 + tid] + red[(1 * NB + bb) * 256 + tid]) +
-              (red[(2 * NB + bb) * 256 + tid] + red[(3 * NB + bb) * 256 + tid]);
-    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
-    if (b < B && n < N) {
-      if (e.bias) v += e.bias[n];
-      if (e.act == 1) v = gelu_erf(v);
-      const int64_t idx = (int64_t)b * e.ldc + n;
-      if (e.out_f32) e.out_f32[idx] = v;
-      if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
-    }
-  }
-}
-
-bool launch_gemm_skinny_ln(const bf16_t* Wsh, const float* xf, const float* gamma, const float* beta, int B, int N, int K,
-                           const GemmEpi& e, hipStream_t s) {
-  if (B < 1 || B > 32 || K % 128 != 0 || K > 1280 || e.residual || e.rowtab) return false;
-  const int NB = B <= 16 ? 1 : 2;
-  const size_t lds = (size_t)NB * 16 * (K * 2 + 16) + (size_t)4 * NB * 256 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_skinny_ln_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)gemm_skinny_ln_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  dim3 grid((N + 15) / 16);
-  if (NB == 1) hipLaunchKernelGGL(gemm_skinny_ln_kernel<1>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
-  else hipLaunchKernelGGL(gemm_skinny_ln_kernel<2>, grid, dim3(256), lds, s, Wsh, xf, gamma, beta, B, N, K, e);
-  return true;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// LayerNorm on the fly.  The residual GEMM that finishes a row block also accumulates sum(x), sum(x^2)
-// per row (GemmEpi::stats_out, two float atomics per row per workgroup), so the consumer needs no pass
-// over x: it loads its f32 x fragment, applies (x - mean) * rstd * gamma + beta in registers, rounds to
-// bf16 and feeds the MFMA.  This removes the three standalone LayerNorm launches per decoder layer
-// (each cost a launch boundary + a DRAM round trip, ~7 us in the profile) without the per-workgroup
-// re-normalisation of the LDS-staged variant above.  Variance = E[x^2] - mean^2 in f32.
-// ------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(256) void gemm_skinny_lnx_kernel(const bf16_t* __restrict__ Wsh, const float* __restrict__ xf,
-                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, int B, int N, int K, GemmEpi e) {
-  constexpr int U = 5;
-  __shared__ float red[4][NB][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb = blockIdx.x;
-  const int kb_per = K / 32;
-  const int steps = kb_per / 4;
-  const int kb0 = wave * steps;
-  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * kb_per + kb0) * 64 + lane;
-  const int koff = kb0 * 32 + 8 * (lane >> 4);
-  const float* xp[NB];
-  float mean[NB], rstd[NB];
-  const float invK = 1.0f / K;
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-    const int b = min(bb * 16 + (lane & 15), B - 1);
-    xp[bb] = xf + (int64_t)b * K + koff;
-    const float s1 = stats[2 * b], s2 = stats[2 * b + 1];
-    mean[bb] = s1 * invK;
-    rstd[bb] = rsqrtf(fmaxf(s2 * invK - mean[bb] * mean[bb], 0.f) + 1e-5f);
-  }
-  const float* gp = gamma + koff;
-  const float* bp = beta + koff;
-  f32x4 acc[NB];
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i0 = 0; i0 < steps; i0 += U) {
-    u32x4 w[U];
-    float4 xv[U][NB][2], gv[U][2], bv[U][2];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u, steps - 1);  // clamped: loads are unconditional, the MFMA is skipped past the end
-      w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64);
-      gv[u][0] = *(const float4*)(gp + i * 32); gv[u][1] = *(const float4*)(gp + i * 32 + 4);
-      bv[u][0] = *(const float4*)(bp + i * 32); bv[u][1] = *(const float4*)(bp + i * 32 + 4);
-#pragma unroll
-      for (int bb = 0; bb < NB; ++bb) {
-        xv[u][bb][0] = *(const float4*)(xp[bb] + i * 32);
-        xv[u][bb][1] = *(const float4*)(xp[bb] + i * 32 + 4);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (i0 + u < steps) {
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb) {
-          // LN(x) = x * (rstd * gamma) + (beta - mean * rstd * gamma); hardware bf16 pack (v_cvt_pk_bf16_f32)
-          const float r = rstd[bb], mr = -mean[bb] * rstd[bb];
-          const float4 x0 = xv[u][bb][0], x1 = xv[u][bb][1];
-          const float4 g0 = gv[u][0], g1 = gv[u][1], c0 = bv[u][0], c1 = bv[u][1];
-          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-          u32x4 xb;
-          { bf2 t = {(__bf16)fmaf(fmaf(x0.x, r, mr), g0.x, c0.x), (__bf16)fmaf(fmaf(x0.y, r, mr), g0.y, c0.y)}; xb[0] = __builtin_bit_cast(uint32_t, t); }
-          { bf2 t = {(__bf16)fmaf(fmaf(x0.z, r, mr), g0.z, c0.z), (__bf16)fmaf(fmaf(x0.w, r, mr), g0.w, c0.w)}; xb[1] = __builtin_bit_cast(uint32_t, t); }
-          { bf2 t = {(__bf16)fmaf(fmaf(x1.x, r, mr), g1.x, c1.x), (__bf16)fmaf(fmaf(x1.y, r, mr), g1.y, c1.y)}; xb[2] = __builtin_bit_cast(uint32_t, t); }
-          { bf2 t = {(__bf16)fmaf(fmaf(x1.z, r, mr), g1.z, c1.z), (__bf16)fmaf(fmaf(x1.w, r, mr), g1.w, c1.w)}; xb[3] = __builtin_bit_cast(uint32_t, t); }
-          acc[bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(s16x8*)&w[u], *(s16x8*)&xb, acc[bb], 0, 0, 0);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][bb][(lane & 15) * 16 + (lane >> 4) * 4 + r] = acc[bb][r];
-  __syncthreads();
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-    float v = (red[0][bb][tid] + red[1][bb][tid]) + (red[2][bb][tid] + red[3][bb][tid]);
-    const int b = bb * 16 + (tid >> 4), n = nb * 16 + (tid & 15);
-    if (b < B && n < N) {
-      if (e.bias) v += e.bias[n];
-      if (e.act == 1) v = gelu_erf(v);
-      const int64_t idx = (int64_t)b * e.ldc + n;
-      if (e.out_f32) e.out_f32[idx] = v;
-      if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(v);
-    }
-  }
-}
-
-bool launch_gemm_skinny_lnx(const bf16_t* Wsh, const float* xf, const float* stats_in, const float* gamma, const float* beta,
-                            int B, int N, int K, const GemmEpi& e, hipStream_t s) {
-  if (B < 1 || B > 32 || K % 128 != 0 || e.residual || e.rowtab || e.stats_out) return false;
-  dim3 grid((N + 15) / 16);
-  if (B <= 16) hipLaunchKernelGGL(gemm_skinny_lnx_kernel<1>, grid, dim3(256), 0, s, Wsh, xf, stats_in, gamma, beta, B, N, K, e);
-  else hipLaunchKernelGGL(gemm_skinny_lnx_kernel<2>, grid, dim3(256), 0, s, Wsh, xf, stats_in, gamma, beta, B, N, K, e);
+  if (nw == 16) hipLaunchKernelGGL(gemm_skinny_kernel<16>, grid, dim3(1024), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else if (nw == 8) hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(512), 0, s, Wsh, x, B, N, K, ksplit, e);
+  else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
   return true;
 }
