@@ -32,7 +32,8 @@ def cpu_baseline(dims, n_new: int, budget_layers: int = 2, budget_steps: int = 6
     from oracle import whisper_ref as R
     from taiwan_tongues_asr_ce_amd import synth
     torch.set_grad_enabled(False)
-    cores = os.cpu_count() or 1
+    # oversubscribing small ops with hundreds of threads is pathologically slow in torch: use at most 32
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     L = budget_layers
     sub = R.Dims(dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, L, L, dims.vocab, dims.n_text_ctx)
@@ -47,14 +48,17 @@ def cpu_baseline(dims, n_new: int, budget_layers: int = 2, budget_steps: int = 6
     t0 = time.perf_counter()
     mel = torch.from_numpy(R.log_mel(clip, dims.n_mels))[None]
     t_mel = time.perf_counter() - t0
+    R.encoder_stem(mel, W)  # warm-up (thread pool, allocator), then time
     t0 = time.perf_counter()
     x = R.encoder_stem(mel, W)
     t_stem = time.perf_counter() - t0
+    R.encoder_layer(x, W, "model.encoder.layers.0", dims.n_heads)  # warm-up
     t0 = time.perf_counter()
     for i in range(L):
         x = R.encoder_layer(x, W, f"model.encoder.layers.{i}", dims.n_heads)
     t_layer = (time.perf_counter() - t0) / L
     enc = R._ln(x, W["model.encoder.layer_norm.weight"], W["model.encoder.layer_norm.bias"])
+    R.cross_kv(enc, W, sub)  # warm-up
     t0 = time.perf_counter()
     xkv = R.cross_kv(enc, W, sub)
     t_xkv = (time.perf_counter() - t0) / L
@@ -109,7 +113,8 @@ def main():
     B = args.batch
     eng = Engine(dims, COMPUTE_BF16 if args.compute == "bf16" else COMPUTE_F32, B, device=local)
     t_load = time.perf_counter()
-    if world > 1:
+    if world > 1 and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
+        # north_star: rank 0 owns the checkpoint, the others receive it over RCCL (xGMI broadcast, 256 MB buckets)
         broadcast_weights(eng, dims, src_iter=synth.iter_weights(dims) if rank == 0 else None, device=local)
     else:
         eng.load_weights(synth.iter_weights(dims))
@@ -159,8 +164,9 @@ def main():
         roof = {"kernel": "cross_attn_decode_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
                 "avg_launch_us": round(k["ms"] * 1e3, 2), "bytes_per_launch": k["bytes"]}
-        g = eng.bench_kernel("enc_gemm_fc1", B, iters=10)
-        enc_tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+        # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time
+        gs = [eng.bench_kernel(n, B, iters=10) for n in ("enc_gemm_qkv", "enc_gemm_out", "enc_gemm_fc1", "enc_gemm_fc2")]
+        enc_tf = sum(x["flops"] for x in gs) / (sum(x["ms"] for x in gs) * 1e-3) / 1e12
         ph = {kk: round(float(np.mean([p[kk] for p in phases])), 2) for kk in phases[0]}
         out = {
             "metric": "audio-sec/s (RTF) whisper-large-v3 greedy, 30 s clips, batch 32; 1/2/4/8 GPU",
@@ -174,7 +180,7 @@ def main():
                        "clips_per_gpu": B, "new_tokens": args.new_tokens, "parallelism": f"dp{world}",
                        "phase_ms": ph, "weight_load_s": round(t_load, 1)},
             "roofline": roof,
-            "mfma": {"kernel": "encoder fc1 GEMM", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
+            "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
                      "frac": round(enc_tf / 2500.0, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

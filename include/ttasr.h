@@ -129,7 +129,7 @@ int ttasr_phase_ms(ttasr_ctx* ctx, float out_ms[4]);
 /* Re-launches one named hot kernel `iters` times on the context's stream with the state left by the
  * last encode/generate (B clips) and returns its average duration measured with hipEvents, plus the
  * algorithmic bytes and flops one launch moves/does.  Names: "xattn" (decoder cross-attention),
- * "enc_gemm_fc1", "enc_attn", "dec_gemm_fc1", "logits_gemm". */
+ * "enc_gemm_qkv", "enc_gemm_out", "enc_gemm_fc1", "enc_gemm_fc2", "enc_attn", "dec_gemm_fc1", "logits_gemm". */
 int ttasr_bench_kernel(ttasr_ctx* ctx, const char* name, int32_t B, int32_t iters, float* out_avg_ms,
                        double* out_bytes_per_launch, double* out_flops_per_launch);
 /* Device-wide synchronisation of the context's stream. */

@@ -866,6 +866,11 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       g.epi.ldc = 3 * c->d; g.epi.bias = c->enc[0].bqkv; g.epi.out_t = c->qkv;
       if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
       bytes = ((double)B * T_ * 4 * d + 3 * d * d) * e; flops = 2.0 * B * T_ * d * 3 * d;
+    } else if (k == "enc_gemm_out") {
+      GemmArgs g; g.A = c->att; g.W = c->enc[0].wo; g.M = B * c->T; g.N = c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
+      g.epi.ldc = c->d; g.epi.bias = c->enc[0].bo; g.epi.residual = c->x; g.epi.out_f32 = c->x;
+      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      bytes = ((double)B * T_ * d + d * d) * e + 8.0 * B * T_ * d; flops = 2.0 * B * T_ * d * d;
     } else if (k == "enc_gemm_fc2") {
       GemmArgs g; g.A = c->mid; g.W = c->enc[0].w2; g.M = B * c->T; g.N = c->d; g.K = c->ffn; g.lda = c->ffn; g.ldw = c->ffn;
       g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2; g.epi.residual = c->x; g.epi.out_f32 = c->x;
