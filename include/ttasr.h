@@ -113,6 +113,16 @@ int ttasr_get_cross_kv(ttasr_ctx* ctx, int32_t layer, int32_t which /*0 K, 1 V*/
 int ttasr_generate(ttasr_ctx* ctx, int32_t B, const int32_t* prompt_host, const int32_t* prompt_len_host,
                    int32_t max_prompt, const ttasr_gen_opts* opts, int32_t* out_tokens_host, int32_t* out_len_host,
                    float* out_sum_logprob_host, float* out_no_speech_host);
+/* Beam search (the reference call sites pass beam_size=5: asr_core.py:164, file_asr.py:462,
+ * faster_whisper_asr.py:144).  n_audio clips x `beam` hypotheses = rows of the decode batch (<= max_batch, and
+ * <= 32 for the bf16 fast path); the `beam` rows of a clip share its cross-attention K/V, and a re-index of the
+ * hypotheses permutes the self-attention page tables (copy-on-write of the one partially filled page) instead
+ * of copying caches.  prompt_host: [n_audio][prompt_len] (same length for every clip).  Candidate selection
+ * follows Whisper's published beam search (top beam+1 per hypothesis, EOT hypotheses go to a finished pool of
+ * round(beam * patience), winner = max sum_logprob / length).  Outputs as ttasr_generate (EOT stripped). */
+int ttasr_generate_beam(ttasr_ctx* ctx, int32_t n_audio, int32_t beam, const int32_t* prompt_host, int32_t prompt_len,
+                        const ttasr_gen_opts* opts, float patience, int32_t* out_tokens_host, int32_t* out_len_host,
+                        float* out_sum_logprob_host, float* out_no_speech_host);
 /* Step-level access for parity tests: reset the self-attention cache, then feed one token per row per
  * call; logits_host (optional) receives raw float32 [B][vocab] for the position just fed. */
 int ttasr_decode_reset(ttasr_ctx* ctx, int32_t B);

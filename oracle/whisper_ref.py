@@ -376,3 +376,96 @@ def transcribe_tokens(pcm_batch: Sequence[np.ndarray], W: Dict[str, torch.Tensor
     mel = torch.from_numpy(np.stack([log_mel(p, dims.n_mels, n_samples) for p in pcm_batch]))
     enc = encoder_forward(mel, W, dims)
     return greedy_decode(enc, prompt, W, dims, rules, max_new_tokens, no_speech_token, sot_index)
+
+
+# --------------------------------------------------------------------------------------------------
+# a10 (beam): beam search as the reference call sites request it (beam_size=5 at asr_core.py:164,
+# file_asr.py:462, faster_whisper_asr.py:144; patience 1, length_penalty 1 are faster-whisper's defaults).
+# CTranslate2's implementation is un-vendored and unpinned; this restates the published Whisper algorithm
+# (openai-whisper decoding.py BeamSearchDecoder + MaximumLikelihoodRanker) that CT2 re-implements:
+# per audio, every live beam proposes its top (beam+1) tokens of log_softmax(processed logits); candidates
+# are keyed by their full token sequence (duplicates collapse), taken in descending cumulative log-prob;
+# those ending in EOT go to the finished pool (capped at round(beam * patience)), the first `beam` others
+# become the new beams; decoding stops when every audio has a full finished pool or the length limit hits;
+# the winner maximises sum_logprob / length (length_penalty = 1).
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class BeamResult:
+    tokens: List[List[int]]          # best hypothesis per audio (EOT stripped)
+    sum_logprob: List[float]
+    no_speech_prob: List[float]
+
+
+def beam_decode(enc: torch.Tensor, prompt: Sequence[int], W: Dict[str, torch.Tensor], dims: Dims, rules: Rules,
+                beam: int, max_new_tokens: int, patience: float = 1.0, no_speech_token: Optional[int] = None,
+                sot_index: int = 0) -> BeamResult:
+    A = enc.shape[0]
+    R = A * beam
+    xkv_a = cross_kv(enc, W, dims)
+    xkv = [(k.repeat_interleave(beam, dim=0), v.repeat_interleave(beam, dim=0)) for k, v in xkv_a]
+    cache = SelfCache.empty(dims.dec_layers)
+    no_speech = [0.0] * A
+    logits = None
+    for j, t in enumerate(prompt):
+        logits = decoder_forward(torch.full((R, 1), t, dtype=torch.long), cache, xkv, W, dims)[:, -1]
+        if no_speech_token is not None and j == sot_index:
+            no_speech = torch.softmax(logits.float(), dim=-1)[::beam, no_speech_token].tolist()
+    seqs: List[List[int]] = [[] for _ in range(R)]
+    sums = [0.0] * R
+    max_cand = round(beam * patience)
+    finished: List[Dict[Tuple[int, ...], float]] = [dict() for _ in range(A)]
+    for _ in range(max_new_tokens):
+        lps = []
+        for r in range(R):
+            s = apply_rules(logits[r], seqs[r], rules)
+            lps.append(torch.log_softmax(s, dim=-1))
+        next_seqs, next_sums, src = [], [], []
+        for a in range(A):
+            scores: Dict[Tuple[int, ...], float] = {}
+            sources: Dict[Tuple[int, ...], int] = {}
+            for j in range(beam):
+                r = a * beam + j
+                top = torch.topk(lps[r], beam + 1)
+                for lp, tok in zip(top.values.tolist(), top.indices.tolist()):
+                    key = tuple(seqs[r] + [tok])
+                    val = sums[r] + lp
+                    if key not in scores or val > scores[key]:  # identical sequences collapse (dict semantics)
+                        scores[key] = val
+                        sources[key] = r
+            saved = 0
+            fin_new = {}
+            for key in sorted(scores, key=lambda k: (-scores[k], k)):
+                if key[-1] == rules.eot:
+                    fin_new[key] = scores[key]
+                else:
+                    next_seqs.append(list(key)); next_sums.append(scores[key]); src.append(sources[key])
+                    saved += 1
+                    if saved == beam:
+                        break
+            for key in sorted(fin_new, key=lambda k: (-fin_new[k], k)):
+                if len(finished[a]) >= max_cand:
+                    break
+                finished[a][key] = fin_new[key]
+            while saved < beam:  # fewer than `beam` live candidates (tiny vocabularies): pad with the last one
+                next_seqs.append(list(next_seqs[-1])); next_sums.append(-1e30); src.append(src[-1]); saved += 1
+        seqs, sums = next_seqs, next_sums
+        idx = torch.tensor(src, dtype=torch.long)
+        for l in range(dims.dec_layers):
+            cache.k[l] = cache.k[l].index_select(0, idx)
+            cache.v[l] = cache.v[l].index_select(0, idx)
+        if all(len(f) >= max_cand for f in finished) or cache.length >= dims.n_text_ctx:
+            break
+        nxt = torch.tensor([s[-1] for s in seqs], dtype=torch.long)[:, None]
+        logits = decoder_forward(nxt, cache, xkv, W, dims)[:, -1]
+    out_t, out_s = [], []
+    for a in range(A):
+        pool = dict(finished[a])
+        if len(pool) < beam:  # not enough finished hypotheses: add the live beams, best first
+            for j in sorted(range(beam), key=lambda j: -sums[a * beam + j]):
+                if len(pool) >= beam:
+                    break
+                pool.setdefault(tuple(seqs[a * beam + j]), sums[a * beam + j])
+        best = max(pool, key=lambda k: (pool[k] / max(len(k), 1), tuple(-t for t in k)))
+        out_t.append([t for t in best if t != rules.eot])
+        out_s.append(pool[best])
+    return BeamResult(out_t, out_s, no_speech)

@@ -120,10 +120,18 @@ template <typename T>
 void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
 template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
-                             int64_t pool_layer_off, const int32_t* step, T* out /*[B][d]*/, int B, int H, hipStream_t s);
+                             int64_t pool_layer_off, int identity_pages, const int32_t* step, T* out /*[B][d]*/, int B, int H,
+                             hipStream_t s);
 template <typename T>
-void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B][H][Tk][64]*/, T* out, int B, int H,
-                              int Tk, hipStream_t s);
+void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s);
+template <typename T>
+void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B / kv_div][H][Tk][64]*/, T* out, int B, int H,
+                              int Tk, int kv_div, hipStream_t s);
+// beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
+// per-row history state uploaded by the host)
+struct BeamRowState { const int32_t *n_sampled, *last_tok, *pen_tok, *last_ts; const uint8_t* mask; };
+void launch_beam_topk(const float* logits, BeamRowState st, RuleParams rp, int R, int k, float* out_lp /*[R][k]*/,
+                      int32_t* out_id /*[R][k]*/, float* out_no_speech /*[R] or null*/, hipStream_t s);
 void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows /*nullable*/, hipStream_t s);
 void launch_advance(int32_t* step, hipStream_t s);
 template <typename T> void launch_cast(const float* in, T* out, int64_t n, hipStream_t s);

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <map>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -74,6 +76,10 @@ struct ttasr_ctx {
   void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
   float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
   float* rows_out = nullptr;
+  int kv_div = 1;            // rows per clip sharing one cross-KV (beam width); 1 for greedy
+  int identity_pages = 1;    // page_table is the identity map (greedy): the self-attention kernel computes page ids
+  int32_t* pairs_dev = nullptr;  // beam search: copy-on-write page pairs
+  float* topk_lp = nullptr; int32_t* topk_id = nullptr; int32_t* row_state = nullptr;  // beam search scratch
   int skip_mask = 0;  // TTASR_SKIP: timing experiments only (1 LN, 2 decode GEMMs, 4 self-attn, 8 cross-attn, 16 select)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
@@ -84,7 +90,7 @@ struct ttasr_ctx {
   float phase_ms[4]{0, 0, 0, 0};
 
   // decode-step graphs keyed by (B, with_logits)
-  struct GraphKey { int B; int mode; hipGraphExec_t exec; };
+  struct GraphKey { int B; int mode; int variant; hipGraphExec_t exec; };
   std::vector<GraphKey> graphs;
   RuleParams rp{};
 };
@@ -294,6 +300,9 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(dalloc(c, &c->st.no_speech, B * 4)); TRY(dalloc(c, &c->st.out_tokens, (size_t)B * c->max_new_alloc * 4));
   TRY(dalloc(c, &c->prompt_dev, (size_t)B * c->max_prompt_alloc * 4)); TRY(dalloc(c, &c->plen_dev, B * 4));
   TRY(dalloc(c, &c->mask_dev, (size_t)c->V + 16));
+  TRY(dalloc(c, &c->pairs_dev, (size_t)B * 2 * 4));
+  TRY(dalloc(c, &c->topk_lp, (size_t)B * 8 * 4)); TRY(dalloc(c, &c->topk_id, (size_t)B * 8 * 4));
+  TRY(dalloc(c, &c->row_state, (size_t)B * 4 * 4));
   c->st.mask = c->mask_dev;
   HIPCHK(c, hipHostMalloc((void**)&c->pinned_i32, 4096));
   // mel constants
@@ -416,12 +425,12 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
     { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv;
       dec_ln_gemm<T>(c, L.ln1g, L.ln1b, B, g, L.wqkv_sh); }
     if (!(c->skip_mask & 4)) launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
-                               (int64_t)l * c->pool_layer_elems, c->st.step, (T*)c->datt, B, c->H, s);
+                               (int64_t)l * c->pool_layer_elems, c->identity_pages, c->st.step, (T*)c->datt, B, c->H, s);
     { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wo_sh); }
     { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq;
       dec_ln_gemm<T>(c, L.ln2g, L.ln2b, B, g, L.wqx_sh); }
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
-    if (!(c->skip_mask & 8)) launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, s);
+    if (!(c->skip_mask & 8)) launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, c->kv_div, s);
     { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wox_sh); }
     { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid;
       dec_ln_gemm<T>(c, L.ln3g, L.ln3b, B, g, L.w1_sh); }
@@ -441,8 +450,9 @@ int step_graph(ttasr_ctx* c, int B, int mode) {
     if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
     return 0;
   }
+  const int variant = c->kv_div * 2 + c->identity_pages;
   for (auto& g : c->graphs)
-    if (g.B == B && g.mode == mode) { HIPCHK(c, hipGraphLaunch(g.exec, c->stream)); return 0; }
+    if (g.B == B && g.mode == mode && g.variant == variant) { HIPCHK(c, hipGraphLaunch(g.exec, c->stream)); return 0; }
   hipGraph_t graph;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
@@ -450,7 +460,7 @@ int step_graph(ttasr_ctx* c, int B, int mode) {
   hipGraphExec_t exec;
   HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   hipGraphDestroy(graph);
-  c->graphs.push_back({B, mode, exec});
+  c->graphs.push_back({B, mode, variant, exec});
   HIPCHK(c, hipGraphLaunch(exec, c->stream));
   return 0;
 }
@@ -788,6 +798,165 @@ int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t
   return TTASR_OK;
 }
 
+int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
+                        float patience, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  if (!c) return TTASR_E_INVALID;
+  if (beam < 1 || beam > 7 || A < 1) return fail(c, TTASR_E_INVALID, "beam must be 1..7 and n_audio >= 1");
+  const int R = A * beam;
+  TRY(check_ready(c, R));
+  if (!prompt || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (A > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, A);
+  if (plen < 1 || plen >= c->cfg.n_text_ctx) return fail(c, TTASR_E_INVALID, "prompt_len %d", plen);
+  for (int i = 0; i < A * plen; ++i)
+    if (prompt[i] < 0 || prompt[i] >= c->V) return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
+  RuleParams old_rp = c->rp;
+  TRY(upload_rules(c, o, plen));
+  if (memcmp(&old_rp, &c->rp, sizeof old_rp) != 0) drop_graphs(c);
+  TRY(reset_search(c, R));
+  c->st.prompt = nullptr; c->st.prompt_len = nullptr;
+  c->B_dec = R;
+  c->kv_div = beam; c->identity_pages = 0;
+  struct Restore { ttasr_ctx* c; ~Restore() { c->kv_div = 1; c->identity_pages = 1; } } restore{c};
+  hipStream_t s = c->stream;
+  const int pps = c->pages_per_seq, n_pages = c->maxB * pps, max_new = c->rp.max_new, K = beam + 1;
+  const int max_cand = std::max(1, (int)std::lround(beam * patience));
+  std::vector<int32_t> tbl((size_t)R * pps, -1), refcnt(n_pages, 0), free_pages, cur_tok(R), pairs;
+  std::vector<std::vector<int>> seqs(R);
+  std::vector<double> sums(R, 0.0);
+  std::vector<std::map<std::vector<int>, double>> finished(A);
+  std::vector<float> h_lp((size_t)R * K), h_ns(R, 0.f);
+  std::vector<int32_t> h_id((size_t)R * K), h_state((size_t)4 * R);
+  auto rebuild_free = [&](int upto_idx) {
+    std::fill(refcnt.begin(), refcnt.end(), 0);
+    for (int r = 0; r < R; ++r)
+      for (int j = 0; j <= upto_idx && j < pps; ++j)
+        if (tbl[(size_t)r * pps + j] >= 0) refcnt[tbl[(size_t)r * pps + j]]++;
+    free_pages.clear();
+    for (int p = n_pages - 1; p >= 0; --p) if (refcnt[p] == 0) free_pages.push_back(p);
+  };
+  rebuild_free(-1);
+  for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen];
+  hipEventRecord(c->ev[5], s);
+  bool stop = false;
+  for (int pos = 0; pos < c->cfg.n_text_ctx && !stop; ++pos) {
+    // 1. the page this step writes must exist and be private to the row (copy-on-write after a re-index)
+    const int j = pos / 16;
+    pairs.clear();
+    for (int r = 0; r < R; ++r) {
+      int32_t& pg = tbl[(size_t)r * pps + j];
+      if (pos % 16 == 0 || pg < 0) {
+        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
+        pg = free_pages.back(); free_pages.pop_back(); refcnt[pg] = 1;
+      } else if (refcnt[pg] > 1) {
+        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
+        const int32_t np = free_pages.back(); free_pages.pop_back();
+        pairs.push_back(pg); pairs.push_back(np);
+        refcnt[pg]--; refcnt[np] = 1; pg = np;
+      }
+    }
+    if (!pairs.empty()) {
+      HIPCHK(c, hipMemcpyAsync(c->pairs_dev, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
+      if (c->bf16) launch_copy_pages<bf16_t>((bf16_t*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s);
+      else launch_copy_pages<float>((float*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s);
+    }
+    {  // page tables are stored [row][pps] with unused entries clamped to a valid page id
+      std::vector<int32_t> up(tbl);
+      for (auto& v : up) if (v < 0) v = 0;
+      HIPCHK(c, hipMemcpyAsync(c->page_table, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, cur_tok.data(), R * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(c, hipStreamSynchronize(s));  // `up` is a stack temporary
+    }
+    // 2. one decoder step over the R rows (logits only; the search itself runs on the host)
+    TRY(step_graph(c, R, 1));
+    const bool sampling = pos + 1 >= plen;
+    const bool want_ns = o->no_speech >= 0 && pos == o->sot_index && out_ns;
+    if (!sampling && !want_ns) {
+      for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pos + 1];
+      continue;
+    }
+    for (int r = 0; r < R; ++r) {
+      int last = -1, pen = -1, lts = -1;
+      for (int t : seqs[r]) { pen = last; last = t; if (t >= o->timestamp_begin) lts = t; }
+      h_state[r] = (int)seqs[r].size(); h_state[R + r] = last; h_state[2 * R + r] = pen; h_state[3 * R + r] = lts;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->row_state, h_state.data(), (size_t)4 * R * 4, hipMemcpyHostToDevice, s));
+    BeamRowState bs{c->row_state, c->row_state + R, c->row_state + 2 * R, c->row_state + 3 * R, c->mask_dev};
+    launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, want_ns ? c->st.no_speech : nullptr, s);
+    HIPCHK(c, hipMemcpyAsync(h_lp.data(), c->topk_lp, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h_id.data(), c->topk_id, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
+    if (want_ns) HIPCHK(c, hipMemcpyAsync(h_ns.data(), c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (!sampling) {
+      for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pos + 1];
+      continue;
+    }
+    // 3. candidate selection per clip (Whisper BeamSearchDecoder semantics; identical sequences collapse)
+    std::vector<std::vector<int>> nseq; std::vector<double> nsum; std::vector<int> src;
+    for (int a = 0; a < A; ++a) {
+      std::map<std::vector<int>, std::pair<double, int>> cand;
+      for (int b = 0; b < beam; ++b) {
+        const int r = a * beam + b;
+        for (int q = 0; q < K; ++q) {
+          const int tok = h_id[(size_t)r * K + q];
+          if (tok < 0) continue;
+          std::vector<int> key(seqs[r]); key.push_back(tok);
+          const double val = sums[r] + (double)h_lp[(size_t)r * K + q];
+          auto it = cand.find(key);
+          if (it == cand.end() || val > it->second.first) cand[key] = {val, r};
+        }
+      }
+      std::vector<std::pair<double, const std::vector<int>*>> order;
+      for (auto& kv : cand) order.push_back({kv.second.first, &kv.first});
+      std::sort(order.begin(), order.end(), [](auto& x, auto& y) { return x.first != y.first ? x.first > y.first : *x.second < *y.second; });
+      int saved = 0;
+      std::vector<std::pair<double, const std::vector<int>*>> fin_new;
+      for (auto& e : order) {
+        if (e.second->back() == o->eot) { fin_new.push_back(e); continue; }
+        nseq.push_back(*e.second); nsum.push_back(e.first); src.push_back(cand[*e.second].second);
+        if (++saved == beam) break;
+      }
+      for (auto& e : fin_new) { if ((int)finished[a].size() >= max_cand) break; finished[a][*e.second] = e.first; }
+      if (saved == 0) return fail(c, TTASR_E_INVALID, "beam search: no live candidate (every token masked)");
+      while (saved < beam) { nseq.push_back(nseq.back()); nsum.push_back(-1e30); src.push_back(src.back()); ++saved; }
+    }
+    // 4. re-index: hypotheses inherit their parent's page list (shared pages; refcounts rebuilt)
+    std::vector<int32_t> ntbl((size_t)R * pps, -1);
+    for (int r = 0; r < R; ++r)
+      for (int q = 0; q <= j; ++q) ntbl[(size_t)r * pps + q] = tbl[(size_t)src[r] * pps + q];
+    tbl.swap(ntbl);
+    rebuild_free(j);
+    seqs.swap(nseq); sums.swap(nsum);
+    for (int r = 0; r < R; ++r) cur_tok[r] = seqs[r].back();
+    bool all_full = true;
+    for (int a = 0; a < A; ++a) all_full &= (int)finished[a].size() >= max_cand;
+    if (all_full || (int)seqs[0].size() >= max_new) stop = true;
+  }
+  hipEventRecord(c->ev[6], s);
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
+  for (int a = 0; a < A; ++a) {
+    std::map<std::vector<int>, double> pool(finished[a]);
+    if ((int)pool.size() < beam) {
+      std::vector<int> idx(beam);
+      for (int b = 0; b < beam; ++b) idx[b] = b;
+      std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return sums[a * beam + x] > sums[a * beam + y]; });
+      for (int b : idx) { if ((int)pool.size() >= beam) break; pool.insert({seqs[a * beam + b], sums[a * beam + b]}); }
+    }
+    const std::vector<int>* best = nullptr; double best_v = -1e300, best_sum = 0;
+    for (auto& kv : pool) {
+      const double v = kv.second / std::max<size_t>(kv.first.size(), 1);
+      if (!best || v > best_v) { best = &kv.first; best_v = v; best_sum = kv.second; }
+    }
+    int n = 0;
+    for (int t : *best) if (t != o->eot && n < max_new) out_tokens[(size_t)a * max_new + n++] = t;
+    out_len[a] = n;
+    if (out_lp) out_lp[a] = (float)best_sum;
+    if (out_ns) out_ns[a] = h_ns[a * beam];
+  }
+  return TTASR_OK;
+}
+
 int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int32_t hist_stride, int32_t n,
                       const ttasr_gen_opts* o, float* out_rows, int32_t* out_choice) {
   if (!c) return TTASR_E_INVALID;
@@ -852,9 +1021,9 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       static int layer_rr = 0;  // walk the layers: one layer's K/V (246 MB at B=32) would sit in the Infinity Cache
       const char* Kx = (const char*)c->xkv + (size_t)(layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
       if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
-                                                    (bf16_t*)c->datt, B, c->H, c->T, s);
+                                                    (bf16_t*)c->datt, B, c->H, c->T, 1, s);
       else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
-                                           (float*)c->datt, B, c->H, c->T, s);
+                                           (float*)c->datt, B, c->H, c->T, 1, s);
       bytes = (double)B * (2.0 * T_ * d + 2.0 * d) * e; flops = (double)B * 4.0 * T_ * d;
     } else if (k == "enc_gemm_fc1") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].w1; g.M = B * c->T; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;

@@ -211,14 +211,32 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
 }
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
-                             const int32_t* step, T* out, int B, int H, hipStream_t s) {
-  // the engine's page table is the identity map until beam search re-indexes it
+                             int identity_pages, const int32_t* step, T* out, int B, int H, hipStream_t s) {
+  // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
   hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, 1, step, out, H);
+                     pages_per_seq, identity_pages, step, out, H);
 }
-template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, const int32_t*, float*, int,
+
+// copy-on-write of partially filled KV pages after a beam re-index: pairs (src, dst) x all layers
+template <typename T>
+__global__ __launch_bounds__(256) void copy_pages_kernel(T* __restrict__ pool, const int32_t* __restrict__ pairs, int H,
+                                                         int64_t layer_elems) {
+  const int src = pairs[2 * blockIdx.x], dst = pairs[2 * blockIdx.x + 1];
+  const int64_t page_elems = (int64_t)2 * H * PAGE * 64;
+  const uint4* s = (const uint4*)(pool + blockIdx.y * layer_elems + src * page_elems);
+  uint4* d = (uint4*)(pool + blockIdx.y * layer_elems + dst * page_elems);
+  const int n = (int)(page_elems * sizeof(T) / 16);
+  for (int i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+template <typename T>
+void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s) {
+  if (n_pairs > 0) hipLaunchKernelGGL(copy_pages_kernel<T>, dim3(n_pairs, n_layers), dim3(256), 0, s, pool, pairs_dev, H, layer_elems);
+}
+template void launch_copy_pages<float>(float*, const int32_t*, int, int, int, int64_t, hipStream_t);
+template void launch_copy_pages<bf16_t>(bf16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
+template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, const int32_t*, float*, int,
                                              int, hipStream_t);
-template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, const int32_t*, bf16_t*,
+template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, const int32_t*, bf16_t*,
                                               int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
@@ -232,7 +250,8 @@ template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int3
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
-                                                                const T* __restrict__ V, T* __restrict__ out, int H, int Tk) {
+                                                                const T* __restrict__ V, T* __restrict__ out, int H, int Tk,
+                                                                int kv_div) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = 8;
   extern __shared__ float sc[];  // [Tk] scores, then [4][64] partial outputs, [8] reductions
@@ -243,8 +262,9 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
   float* red = part + 4 * 64;   // [8]
   float qv[VEC];
   RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
-  const T* Kp = K + ((int64_t)b * H + h) * Tk * 64;
-  const T* Vp = V + ((int64_t)b * H + h) * Tk * 64;
+  const int bk = b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
+  const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64;
+  const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64;
   float mloc = -1e30f;
   // rows handled by this wave: t = (it*4 + wave)*RPI + rin
   const int n_it = (Tk + 4 * RPI - 1) / (4 * RPI);
@@ -321,9 +341,9 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
   }
 }
 template <typename T>
-void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, hipStream_t s) {
+void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s) {
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL(cross_attn_decode_kernel<T>, dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk);
+  hipLaunchKernelGGL(cross_attn_decode_kernel<T>, dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div);
 }
-template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, hipStream_t);
-template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, hipStream_t);
+template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t);

@@ -171,3 +171,97 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows, hipStream_t s) {
   hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, s, logits, st, rp, out_rows);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Beam search candidate kernel: one workgroup per row.  Applies the same rule stack as select_kernel
+// (row history comes from the host, which owns the beam bookkeeping), then returns the k largest
+// log-softmax values and their ids (ties: lowest id first, as torch.topk on distinct values).
+// k + 2 passes over the V-float row (L2-resident), k <= 8.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict__ logits, BeamRowState st, RuleParams p, int k,
+                                                         float* __restrict__ out_lp, int32_t* __restrict__ out_id,
+                                                         float* __restrict__ out_ns) {
+  __shared__ ArgMax s_am[2][16];
+  __shared__ float s_sum[3][16];
+  __shared__ float s_f[4];
+  __shared__ int s_chosen[8];
+  __shared__ int s_flag;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * p.ldv;
+  RowRule r;
+  r.n = st.n_sampled[b];
+  const int last = st.last_tok[b], pen = st.pen_tok[b], lts = st.last_ts[b];
+  const int tb = p.timestamp_begin;
+  r.last_is_ts = (r.n >= 1 && last >= tb);
+  r.pen_is_ts = (r.n < 2 || pen >= tb);
+  r.ts_floor = (lts >= 0) ? ((r.last_is_ts && !r.pen_is_ts) ? lts : lts + 1) : 0;
+  // pass 1: maxima of the text / timestamp ranges (masked) and of the raw row
+  float m_txt = -INFINITY, m_ts = -INFINITY, m_raw = -INFINITY;
+  for (int i = tid; i < p.V; i += 1024) {
+    const float v = row[i];
+    m_raw = fmaxf(m_raw, v);
+    if (!masked(i, r, p, st.mask)) { if (p.timestamps && i >= tb) m_ts = fmaxf(m_ts, v); else m_txt = fmaxf(m_txt, v); }
+  }
+  m_txt = wave_max(m_txt); m_ts = wave_max(m_ts); m_raw = wave_max(m_raw);
+  if (lane == 0) { s_sum[0][wave] = m_txt; s_sum[1][wave] = m_ts; s_sum[2][wave] = m_raw; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = -INFINITY, c = -INFINITY, d = -INFINITY;
+    for (int w = 0; w < 16; ++w) { a = fmaxf(a, s_sum[0][w]); c = fmaxf(c, s_sum[1][w]); d = fmaxf(d, s_sum[2][w]); }
+    s_f[0] = a; s_f[1] = c; s_f[2] = d;
+  }
+  __syncthreads();
+  const float mx_txt = s_f[0], mx_ts = s_f[1], mx_raw = s_f[2], mx_all = fmaxf(mx_txt, mx_ts);
+  // pass 2: exp sums
+  float sum_txt = 0.f, sum_ts = 0.f, sum_raw = 0.f;
+  for (int i = tid; i < p.V; i += 1024) {
+    const float v = row[i];
+    if (out_ns) sum_raw += __expf(v - mx_raw);
+    if (!masked(i, r, p, st.mask)) { const float e = __expf(v - mx_all); if (p.timestamps && i >= tb) sum_ts += e; else sum_txt += e; }
+  }
+  sum_txt = wave_sum(sum_txt); sum_ts = wave_sum(sum_ts); sum_raw = wave_sum(sum_raw);
+  __syncthreads();
+  if (lane == 0) { s_sum[0][wave] = sum_txt; s_sum[1][wave] = sum_ts; s_sum[2][wave] = sum_raw; }
+  __syncthreads();
+  if (tid == 0) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int w = 0; w < 16; ++w) { t0 += s_sum[0][w]; t1 += s_sum[1][w]; t2 += s_sum[2][w]; }
+    if (out_ns) out_ns[b] = (p.no_speech >= 0) ? __expf(row[p.no_speech] - mx_raw) / t2 : 0.f;
+    const bool force_ts = p.timestamps && t1 > 0.f && (__logf(t1) + mx_all > mx_txt);
+    s_flag = force_ts;
+    s_f[3] = force_ts ? __logf(t1) + mx_all : __logf(t0 + t1) + mx_all;  // logsumexp of the allowed set
+  }
+  __syncthreads();
+  const bool force_ts = s_flag != 0;
+  const float lse = s_f[3];
+  // k rounds of masked argmax, excluding the ids already taken
+  for (int round = 0; round < k; ++round) {
+    ArgMax best{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < p.V; i += 1024) {
+      if (force_ts && i < tb) continue;
+      if (masked(i, r, p, st.mask)) continue;
+      bool taken = false;
+      for (int c = 0; c < round; ++c) taken |= (s_chosen[c] == i);
+      if (taken) continue;
+      best = am_merge(best, ArgMax{row[i], i});
+    }
+    best = am_wave(best);
+    if (lane == 0) s_am[0][wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+      ArgMax x = lane < 16 ? s_am[0][lane] : ArgMax{-INFINITY, 0x7fffffff};
+      x = am_wave(x);
+      if (lane == 0) {
+        s_chosen[round] = x.i;
+        out_lp[b * k + round] = (x.i == 0x7fffffff) ? -INFINITY : x.v - lse;
+        out_id[b * k + round] = (x.i == 0x7fffffff) ? -1 : x.i;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+void launch_beam_topk(const float* logits, BeamRowState st, RuleParams rp, int R, int k, float* out_lp, int32_t* out_id,
+                      float* out_no_speech, hipStream_t s) {
+  hipLaunchKernelGGL(beam_topk_kernel, dim3(R), dim3(1024), 0, s, logits, st, rp, k, out_lp, out_id, out_no_speech);
+}

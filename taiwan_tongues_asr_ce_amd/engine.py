@@ -156,6 +156,22 @@ class Engine:
                                             lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate")
         return GenResult([toks[b, :lens[b]].tolist() for b in range(B)], lp, ns)
 
+    def generate_beam(self, prompts: Sequence[Sequence[int]], beam: int, opts, patience: float = 1.0) -> GenResult:
+        """Beam search over len(prompts) clips (equal-length prompts); rows = clips * beam <= max_batch."""
+        A = len(prompts)
+        plen = len(prompts[0])
+        assert all(len(p) == plen for p in prompts), "beam search needs equal-length prompts"
+        pr = np.asarray(prompts, dtype=np.int32).reshape(A, plen)
+        toks = np.zeros((A, opts.max_new_tokens), dtype=np.int32)
+        lens = np.zeros(A, dtype=np.int32)
+        lp = np.zeros(A, dtype=np.float32)
+        ns = np.zeros(A, dtype=np.float32)
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        self._check(self.lib.ttasr_generate_beam(self.h, A, beam, pr.ctypes.data_as(i32p), plen, C.byref(opts),
+                                                 C.c_float(patience), toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                 lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_beam")
+        return GenResult([toks[a, :lens[a]].tolist() for a in range(A)], lp, ns)
+
     def decode_reset(self, B: int):
         self._check(self.lib.ttasr_decode_reset(self.h, B), "decode_reset")
 

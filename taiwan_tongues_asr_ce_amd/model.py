@@ -126,7 +126,7 @@ def _read_hf_dir(path: str) -> Tuple[WhisperDims, Iterable[Tuple[str, np.ndarray
 
 class WhisperModel:
     def __init__(self, model_size_or_path: str, device: str = "auto", device_index: int = 0,
-                 compute_type: str = "default", max_batch: int = 1, **_unused):
+                 compute_type: str = "default", max_batch: int = 8, **_unused):
         if device not in ("cuda", "auto", "gpu", "hip"):
             raise RuntimeError(f"device={device!r}: this build has only the MI355X HIP path (no CPU fallback)")
         if compute_type not in _COMPUTE_ALIASES:
@@ -244,8 +244,12 @@ class WhisperModel:
             # asr_core.py:156 loads with mono=False; faster-whisper rejects 2-D input the same way
             raise ValueError(f"audio must be mono float32 [n] @16 kHz, got shape {audio.shape}")
         audio = np.ascontiguousarray(audio, dtype=np.float32)
-        if beam_size != 1:
-            warnings.warn("beam search is not implemented yet: decoding greedily (beam_size=1)", stacklevel=2)
+        if beam_size < 1:
+            raise ValueError("beam_size must be >= 1")
+        if beam_size > min(7, self.max_batch):
+            warnings.warn(f"beam_size={beam_size} exceeds this model's row budget (max_batch={self.max_batch}, kernel limit 7): "
+                          "decoding greedily", stacklevel=2)
+            beam_size = 1
         if vad_filter:
             warnings.warn("vad_filter=True: no VAD model in this build, the whole clip is treated as speech", stacklevel=2)
         if word_timestamps:
@@ -260,16 +264,16 @@ class WhisperModel:
             lang_p, all_p = 1.0, None
         info = TranscriptionInfo(language=language, language_probability=lang_p, duration=duration,
                                  duration_after_vad=duration, all_language_probs=all_p,
-                                 transcription_options=dict(beam_size=1, task=task, without_timestamps=without_timestamps,
+                                 transcription_options=dict(beam_size=beam_size, task=task, without_timestamps=without_timestamps,
                                                             condition_on_previous_text=condition_on_previous_text,
                                                             initial_prompt=initial_prompt))
         return self._generate_segments(audio, language, task, condition_on_previous_text, initial_prompt,
                                        without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
-                                       max_initial_timestamp, suppress_blank), info
+                                       max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0)), info
 
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
-                           no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank
-                           ) -> Iterator[Segment]:
+                           no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,
+                           patience=1.0) -> Iterator[Segment]:
         eng, st = self.engine, self.special
         lang_tok = self._lang_token(language)
         n_total = int(np.ceil(len(audio) / HOP)) if len(audio) else 0
@@ -290,7 +294,7 @@ class WhisperModel:
             opts = eng.gen_opts(budget, timestamps=not without_timestamps, sot_index=sot_index,
                                 begin_suppress=[220, st.eot] if suppress_blank else [],
                                 max_initial_timestamp_index=int(round(max_initial_timestamp / 0.02)), check_interval=4)
-            res = eng.generate([prompt], opts)
+            res = eng.generate_beam([prompt], beam_size, opts, patience) if beam_size > 1 else eng.generate([prompt], opts)
             toks = res.tokens[0]
             n_tok = max(len(toks), 1)
             avg_lp = float(res.sum_logprob[0]) / n_tok

@@ -1,0 +1,93 @@
+"""GPU: beam search (reference call sites pass beam_size=5) against the CPU oracle's restatement of the
+published Whisper beam search, f32 compute mode, tokens exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, PRESETS, SpecialTokens
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def _micro_state(boost_eot=0.0):
+    sd = synth.state_dict(PRESETS["micro"])
+    if boost_eot:
+        st = SpecialTokens.for_vocab(512)
+        sd = dict(sd)
+        e = sd["model.decoder.embed_tokens.weight"].copy()
+        e[st.eot] *= boost_eot  # larger norm -> EOT logit has a larger spread -> hypotheses do finish
+        sd["model.decoder.embed_tokens.weight"] = e
+    return sd
+
+
+@pytest.mark.parametrize("boost,beam,patience", [(0.0, 5, 1.0), (4.0, 5, 1.0), (4.0, 3, 2.0), (0.0, 1, 1.0)])
+def test_micro_beam_matches_oracle(golden_dir, boost, beam, patience):
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    g = np.load(os.path.join(golden_dir, "micro.npz"))
+    dims = PRESETS["micro"]
+    st = SpecialTokens.for_vocab(dims.vocab)
+    sd = _micro_state(boost)
+    A = 3
+    e = Engine(dims, COMPUTE_F32, A * beam)
+    e.load_weights(sd.items())
+    e.set_encoder_output(g["enc"])
+    prompt = g["prompt"].tolist()
+    sup, bsup = g["suppress"].tolist(), g["begin_suppress"].tolist()
+    if boost:
+        bsup = [5]  # allow EOT at the first position too
+    opts = e.gen_opts(20, True, suppress=sup, begin_suppress=bsup)
+    res = e.generate_beam([prompt] * A, beam, opts, patience)
+    W = R.to_torch(sd)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=sup,
+                    begin_suppress=bsup, timestamps=True)
+    ref = R.beam_decode(torch.from_numpy(g["enc"]), prompt, W, R.Dims(**dims.as_dict()), rules, beam, 20, patience,
+                        no_speech_token=st.no_speech)
+    assert res.tokens == ref.tokens
+    np.testing.assert_allclose(res.sum_logprob, ref.sum_logprob, atol=5e-3)
+    np.testing.assert_allclose(res.no_speech_prob, ref.no_speech_prob, rtol=1e-3)
+    if beam == 1:
+        greedy = e.generate([prompt] * A, e.gen_opts(20, True, suppress=sup, begin_suppress=bsup, check_interval=1))
+        assert [[t for t in s if t != st.eot] for s in greedy.tokens] == res.tokens
+    e.close()
+
+
+def test_tiny_beam5_f32_and_bf16_runs():
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    dims = PRESETS["tiny"]
+    rd = R.Dims(**dims.as_dict())
+    sd = synth.state_dict(dims)
+    clips = [synth.noise_clip(0), synth.tonal_clip(1)]
+    mel = torch.from_numpy(np.stack([R.log_mel(c, 80) for c in clips]))
+    W = R.to_torch(sd)
+    enc_ref = R.encoder_forward(mel, W, rd)
+    e = Engine(dims, COMPUTE_F32, 10)
+    e.load_weights(sd.items())
+    st = e.special
+    e.log_mel(clips, want_output=False)
+    e.encode(2)
+    prompt = [st.sot, st.lang_zh, st.transcribe]
+    opts = e.gen_opts(12, True)
+    res = e.generate_beam([prompt] * 2, 5, opts)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
+    ref = R.beam_decode(enc_ref, prompt, W, rd, rules, 5, 12)
+    assert res.tokens == ref.tokens
+    # a greedy call after a beam call must still be right (page tables / graph variants restored)
+    g1 = e.generate([prompt] * 2, e.gen_opts(8, True, check_interval=1))
+    gref = R.greedy_decode(enc_ref, prompt, W, rd, rules, 8)
+    assert g1.tokens == gref.tokens
+    e.close()
+    eb = Engine(dims, COMPUTE_BF16, 10)
+    eb.load_weights(sd.items())
+    eb.log_mel(clips, want_output=False)
+    eb.encode(2)
+    rb = eb.generate_beam([prompt] * 2, 5, eb.gen_opts(12, True))
+    assert all(len(t) > 0 for t in rb.tokens) and np.isfinite(rb.sum_logprob).all()
+    # the bf16 hypothesis must be a plausible one: its score under the f32 oracle's model is within 1.0 of the oracle's best
+    assert abs(float(rb.sum_logprob[0]) - ref.sum_logprob[0]) < 1.5
+    eb.close()
