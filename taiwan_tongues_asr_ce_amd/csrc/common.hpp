@@ -120,7 +120,7 @@ template <typename T>
 void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
 template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
-                             int64_t pool_layer_off, int identity_pages, const int32_t* step, T* out /*[B][d]*/, int B, int H,
+                             int64_t pool_layer_off, int identity_pages, int row0, const int32_t* step, T* out /*[B][d]*/, int B, int H,
                              hipStream_t s);
 template <typename T>
 void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s);

@@ -45,6 +45,10 @@ struct ttasr_ctx {
   ttasr_config cfg{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t cur = nullptr;      // stream the schedule helpers enqueue on (stream, or stream2 for the second half-batch)
+  hipStream_t stream2 = nullptr;  // second decode chain (dual half-batch mode)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int dual_min_rows = 32;         // B >= this: split the decode step into two concurrent half-batch chains
   std::string err;
   bool bf16 = false;
   bool finalized = false;
@@ -329,12 +333,12 @@ void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
       const char* v = getenv("TTASR_GEMM");  // "v1": 128x128 two-stage kernel, default: 256x128 three-stage
-      if ((!v || v[1] == '3') && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->stream); return; }
-      if (!(v && v[1] == '1') && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->stream); return; }
-      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->stream); return; }
+      if ((!v || v[1] == '3') && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->cur); return; }
+      if (!(v && v[1] == '1') && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->cur); return; }
+      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->cur); return; }
     }
   }
-  launch_gemm_basic<T>(g, c->stream);
+  launch_gemm_basic<T>(g, c->cur);
 }
 
 // decode-step GEMM: B rows against a streamed weight; bf16 uses the fragment-packed skinny kernel
@@ -342,15 +346,15 @@ template <typename T>
 void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
   if (c->skip_mask & 2) return;
   if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, c->stream)) return;
+    if (!c->force_basic && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
   }
-  launch_gemm_basic<T>(g, c->stream);
+  launch_gemm_basic<T>(g, c->cur);
 }
 
 // LayerNorm(x) followed by a decode GEMM (two launches: fusing LN into the GEMM was measured slower)
 template <typename T>
 void dec_ln_gemm(ttasr_ctx* c, const float* g_, const float* b_, int B, const GemmArgs& g, const void* Wsh) {
-  if (!(c->skip_mask & 1)) launch_layernorm<T>(c->dx, g_, b_, (T*)c->dh, B, c->d, c->stream);
+  if (!(c->skip_mask & 1)) launch_layernorm<T>(c->dx, g_, b_, (T*)c->dh, B, c->d, c->cur);
   dec_gemm<T>(c, g, Wsh);
 }
 
@@ -376,7 +380,7 @@ int run_cross_kv(ttasr_ctx* c, int B) {
 template <typename T>
 int run_encoder(ttasr_ctx* c, int B) {
   const int d = c->d, T_ = c->T, F = c->F, M = c->M, ffn = c->ffn;
-  hipStream_t s = c->stream;
+  hipStream_t s = c->cur;
   hipEventRecord(c->ev[2], s);
   {  // conv1 as GEMM over the zero-padded time-major mel image: row t of A = rows t..t+2 of the image
     GemmArgs g; g.A = c->mel_t; g.W = c->conv1_w; g.M = F; g.N = d; g.K = 3 * M; g.lda = M; g.ldw = 3 * M;
@@ -413,36 +417,75 @@ int run_encoder(ttasr_ctx* c, int B) {
   return 0;
 }
 
-// One decoder step for B rows at position *st.step.  mode 0: through logits + select; 1: logits only
-// (test API); 2: no logits (all rows forced by the prompt), select just advances the forced token.
+// One decoder step for rows [row0, row0 + n) at position *st.step, enqueued on c->cur.
+// mode 0: through logits + select; 1: logits only (test API / beam search); 2: no logits (all rows forced by
+// the prompt), select just advances the forced token.
 template <typename T>
-void run_decode_step(ttasr_ctx* c, int B, int mode) {
+void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
   const int d = c->d, ffn = c->ffn;
-  hipStream_t s = c->stream;
-  launch_embed<T>(c->st.cur_tok, c->st.step, (const T*)c->emb, (const T*)c->dpos, c->dx, B, d, s);
+  hipStream_t s = c->cur;
+  const size_t e = c->esz;
+  auto tp = [&](void* base, int64_t width) { return (void*)((char*)base + (size_t)row0 * width * e); };  // T rows
+  float* dx = c->dx + (size_t)row0 * d;
+  void *dh = tp(c->dh, d), *dqkv = tp(c->dqkv, 3 * d), *dq = tp(c->dq, d), *datt = tp(c->datt, d), *dmid = tp(c->dmid, ffn);
+  float* logits = c->logits + (size_t)row0 * c->ldv;
+  auto ln_gemm = [&](const float* g_, const float* b_, const GemmArgs& g, const void* Wsh) {
+    if (!(c->skip_mask & 1)) launch_layernorm<T>(dx, g_, b_, (T*)dh, n, d, s);
+    dec_gemm<T>(c, g, Wsh);
+  };
+  launch_embed<T>(c->st.cur_tok + row0, c->st.step, (const T*)c->emb, (const T*)c->dpos, dx, n, d, s);
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
-    { GemmArgs g = lin_args<T>(c->dh, L.wqkv, B, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->dqkv;
-      dec_ln_gemm<T>(c, L.ln1g, L.ln1b, B, g, L.wqkv_sh); }
-    if (!(c->skip_mask & 4)) launch_self_attn_decode<T>((const T*)c->dqkv, (T*)c->pool, c->page_table, c->pages_per_seq,
-                               (int64_t)l * c->pool_layer_elems, c->identity_pages, c->st.step, (T*)c->datt, B, c->H, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wo, B, d, d); g.epi.bias = L.bo; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wo_sh); }
-    { GemmArgs g = lin_args<T>(c->dh, L.wqx, B, d, d); g.epi.bias = L.bqx; g.epi.out_t = c->dq;
-      dec_ln_gemm<T>(c, L.ln2g, L.ln2b, B, g, L.wqx_sh); }
-    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
-    if (!(c->skip_mask & 8)) launch_cross_attn_decode<T>((const T*)c->dq, Kx, Kx + c->xkv_which_elems, (T*)c->datt, B, c->H, c->T, c->kv_div, s);
-    { GemmArgs g = lin_args<T>(c->datt, L.wox, B, d, d); g.epi.bias = L.box; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.wox_sh); }
-    { GemmArgs g = lin_args<T>(c->dh, L.w1, B, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      dec_ln_gemm<T>(c, L.ln3g, L.ln3b, B, g, L.w1_sh); }
-    { GemmArgs g = lin_args<T>(c->dmid, L.w2, B, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->dx; g.epi.out_f32 = c->dx; dec_gemm<T>(c, g, L.w2_sh); }
+    { GemmArgs g = lin_args<T>(dh, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = dqkv; ln_gemm(L.ln1g, L.ln1b, g, L.wqkv_sh); }
+    if (!(c->skip_mask & 4))
+      launch_self_attn_decode<T>((const T*)dqkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
+                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s);
+    { GemmArgs g = lin_args<T>(datt, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.wo_sh); }
+    { GemmArgs g = lin_args<T>(dh, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = dq; ln_gemm(L.ln2g, L.ln2b, g, L.wqx_sh); }
+    // cross-KV of clip (row / kv_div); a half-batch offset is only used with kv_div == 1
+    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
+    if (!(c->skip_mask & 8))
+      launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s);
+    { GemmArgs g = lin_args<T>(datt, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.wox_sh); }
+    { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; ln_gemm(L.ln3g, L.ln3b, g, L.w1_sh); }
+    { GemmArgs g = lin_args<T>(dmid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.w2_sh); }
   }
   if (mode != 2) {
-    GemmArgs g = lin_args<T>(c->dh, c->emb, B, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
-    g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-    dec_ln_gemm<T>(c, c->dlnf_g, c->dlnf_b, B, g, c->emb_sh);
+    GemmArgs g = lin_args<T>(dh, c->emb, n, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
+    g.epi.out_f32 = logits; g.epi.ldc = c->ldv;
+    ln_gemm(c->dlnf_g, c->dlnf_b, g, c->emb_sh);
   }
-  if (mode != 1 && !(c->skip_mask & 16)) launch_select(c->logits, c->st, c->rp, B, nullptr, s);
-  launch_advance(c->st.step, s);
+  if (mode != 1 && !(c->skip_mask & 16)) {
+    DecState st = c->st;  // row-offset view of the search state
+    st.cur_tok += row0; st.n_sampled += row0; st.last_tok += row0; st.pen_tok += row0; st.last_ts += row0; st.done += row0;
+    st.sum_logprob += row0; st.no_speech += row0; st.out_tokens += (size_t)row0 * c->rp.max_new;
+    if (st.prompt) { st.prompt += (size_t)row0 * c->rp.max_prompt; st.prompt_len += row0; }
+    launch_select(logits, st, c->rp, n, nullptr, s);
+  }
+}
+
+// A decode step is a chain of ~350 launches of 4-8 us each, every one paying a launch boundary and a memory
+// round trip while most of the chip idles; only cross-attention is bandwidth-bound.  For B >= 32 the batch is
+// therefore split into two half-batches whose chains run CONCURRENTLY (two streams forked and joined inside the
+// captured graph): one chain's latency-bound kernels overlap the other's cross-attention stream.  Weights are
+// read twice per step (the second read mostly hits the Infinity Cache), which costs less than the idle time won.
+template <typename T>
+void run_decode_step(ttasr_ctx* c, int B, int mode) {
+  const bool dual = c->stream2 && c->kv_div == 1 && B >= c->dual_min_rows && B % 2 == 0;
+  c->cur = c->stream;
+  if (!dual) {
+    run_decode_rows<T>(c, 0, B, mode);
+  } else {
+    hipEventRecord(c->ev_fork, c->stream);
+    hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
+    run_decode_rows<T>(c, 0, B / 2, mode);
+    c->cur = c->stream2;
+    run_decode_rows<T>(c, B / 2, B / 2, mode);
+    c->cur = c->stream;
+    hipEventRecord(c->ev_join, c->stream2);
+    hipStreamWaitEvent(c->stream, c->ev_join, 0);
+  }
+  launch_advance(c->st.step, c->stream);
 }
 
 int step_graph(ttasr_ctx* c, int B, int mode) {
@@ -560,6 +603,14 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
+  p->cur = p->stream;
+  if (getenv("TTASR_NO_DUAL") == nullptr) {
+    if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess)
+      return die(fail(p, TTASR_E_HIP, "second decode stream creation failed"));
+  }
+  if (getenv("TTASR_DUAL_MIN")) p->dual_min_rows = atoi(getenv("TTASR_DUAL_MIN"));
   int rc = build_weights(p);
   if (rc) return die(rc);
   rc = build_workspaces(p);
@@ -576,6 +627,9 @@ void ttasr_destroy(ttasr_ctx* c) {
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }

@@ -115,8 +115,8 @@ constexpr int PAGE = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
                                                                const int32_t* __restrict__ page_table, int pages_per_seq,
-                                                               int identity_pages, const int32_t* __restrict__ step,
-                                                               T* __restrict__ out, int H) {
+                                                               int identity_pages, int row0,
+                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
   __shared__ float part[4][64];
@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
   RowVec<T>::load(qp + sub * VEC, q);
   RowVec<T>::load(qp + d + sub * VEC, kn);
   RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
-  const int32_t* pt = page_table + b * pages_per_seq;
-  auto page_of = [&](int t) { return identity_pages ? b * pages_per_seq + t / PAGE : pt[t / PAGE]; };
+  const int bg = b + row0;  // global row: qkv / out are already offset to the half-batch, the KV pages are not
+  const int32_t* pt = page_table + bg * pages_per_seq;
+  auto page_of = [&](int t) { return identity_pages ? bg * pages_per_seq + t / PAGE : pt[t / PAGE]; };
   if (wave == 0 && rin == 0) {  // append this step's k, v
     const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
@@ -211,10 +212,10 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
 }
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
-                             int identity_pages, const int32_t* step, T* out, int B, int H, hipStream_t s) {
+                             int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s) {
   // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
   hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, identity_pages, step, out, H);
+                     pages_per_seq, identity_pages, row0, step, out, H);
 }
 
 // copy-on-write of partially filled KV pages after a beam re-index: pairs (src, dst) x all layers
@@ -234,10 +235,10 @@ void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_lay
 }
 template void launch_copy_pages<float>(float*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_copy_pages<bf16_t>(bf16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
-template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, const int32_t*, float*, int,
-                                             int, hipStream_t);
-template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, const int32_t*, bf16_t*,
-                                              int, int, hipStream_t);
+template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, int, const int32_t*, float*,
+                                             int, int, hipStream_t);
+template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
+                                              bf16_t*, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // decoder cross-attention.  K, V: [B][H][Tk][64] (head-major, written by the cross-KV GEMM epilogue), so
