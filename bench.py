@@ -161,8 +161,16 @@ def main():
         # on the engine's own stream (ttasr_bench_kernel), state = the cross-KV left by the last step.
         k = eng.bench_kernel("xattn", B, iters=50)
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately
+        # and committed as profiles/xattn_pmc.json; gfx950 x2 FETCH_SIZE correction applied there)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "xattn_pmc.json")) as f:
+                traffic = round(json.load(f)["traffic_bytes_per_32row_launch"] * B / 32.0)
+        except Exception:
+            pass
         roof = {"kernel": "cross_attn_decode_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "avg_launch_us": round(k["ms"] * 1e3, 2), "bytes_per_launch": k["bytes"]}
         # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time
         gs = [eng.bench_kernel(n, B, iters=10) for n in ("enc_gemm_qkv", "enc_gemm_out", "enc_gemm_fc1", "enc_gemm_fc2")]

@@ -34,7 +34,18 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K 8 KiB | V 8 KiB); reused for the O transpose
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hf = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * FA_QB + wave * 32;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD whole (batch, head)
+  // pairs: its q-blocks then re-read the same K/V from that XCD's L2 instead of each XCD fetching every K/V
+  // from HBM (measured 2.1 GB fetched per launch against 0.37 GB of q/k/v with the naive order).
+  const int nq = gridDim.x, n_bh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + nq * (blockIdx.y + gridDim.y * blockIdx.z);
+  int qb = blockIdx.x, bh = blockIdx.y + gridDim.y * blockIdx.z;
+  if ((n_bh & 7) == 0) {
+    const int xcd = lin & 7, slot = lin >> 3;
+    qb = slot % nq;
+    bh = (slot / nq) * 8 + xcd;
+  }
+  const int b = bh / H, h = bh - b * H, q0 = qb * FA_QB + wave * 32;
   const int d = H * 64;
   const int64_t ld = 3 * (int64_t)d;
   const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 64;
