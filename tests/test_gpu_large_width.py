@@ -1,0 +1,78 @@
+"""GPU parity at whisper-large-v3 WIDTH (d 1280, 20 heads, ffn 5120, 128 mels, vocab 51866) with 2+2 layers,
+so every kernel runs the shapes of the benchmarked configuration (256x256 GEMM tiles with a ragged last M
+tile, 128-bin log-mel + conv stem, 32x32x16 decode GEMMs with K = 1280 / 5120, the 51866-wide vocabulary
+projection) against the CPU oracle; and whisper-small (BASELINE.json configs[1]) at reduced depth."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, WhisperDims
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+LARGE2 = WhisperDims("large-v3-2layer", 128, 1500, 1280, 20, 5120, 2, 2, 51866)
+SMALL2 = WhisperDims("small-2layer", 80, 1500, 768, 12, 3072, 2, 2, 51865)
+
+
+def _run(dims, compute, clips, n_new):
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    sd = synth.state_dict(dims)
+    e = Engine(dims, compute, len(clips))
+    e.load_weights(sd.items())
+    st = e.special
+    mel = e.log_mel(clips)
+    enc = e.encode(len(clips), want_output=True)
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    e.decode_reset(len(clips))
+    step_logits = [e.decode_step([t] * len(clips)) for t in prompt]
+    opts = e.gen_opts(n_new, False, check_interval=1)
+    res = e.generate([prompt] * len(clips), opts)
+    sup = [opts.suppress[i] for i in range(opts.n_suppress)]
+    e.close()
+    return sd, st, mel, enc, step_logits, res, prompt, sup
+
+
+@pytest.mark.parametrize("dims", [LARGE2, SMALL2], ids=["large-v3-width", "small-width"])
+def test_width_parity_f32_and_bf16(dims):
+    rd = R.Dims(**dims.as_dict())
+    clips = [synth.noise_clip(0), synth.tonal_clip(1)]
+    # ---- f32 engine vs f32 oracle: north_star tolerance 1e-3 on logits, tokens exact
+    sd, st, mel, enc, step_logits, res, prompt, sup = _run(dims, COMPUTE_F32, clips, 6)
+    W = R.to_torch(sd)
+    mel_ref = np.stack([R.log_mel(c, dims.n_mels) for c in clips])
+    np.testing.assert_allclose(mel, mel_ref, atol=2e-4)
+    enc_ref = R.encoder_forward(torch.from_numpy(mel_ref), W, rd)
+    np.testing.assert_allclose(enc, enc_ref.numpy(), atol=1e-3)
+    xkv = R.cross_kv(enc_ref, W, rd)
+    cache = R.SelfCache.empty(rd.dec_layers)
+    for t, lg in zip(prompt, step_logits):
+        want = R.decoder_forward(torch.full((2, 1), t), cache, xkv, W, rd)[:, 0].numpy()
+        np.testing.assert_allclose(lg, want, atol=1e-3)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=sup,
+                    begin_suppress=[220, st.eot], timestamps=False)
+    ref = R.greedy_decode(enc_ref, prompt, W, rd, rules, 6)
+    assert res.tokens == ref.tokens
+    # ---- bf16 engine vs the oracle holding bf16-rounded weights.  Tolerances: encoder (LayerNorm-scale
+    # outputs) 0.15 max / 0.012 mean abs; logits 0.08 abs; greedy choice within 0.15 of the oracle's best logit
+    sd, st, mel, enc_b, step_logits_b, res_b, prompt, sup = _run(dims, COMPUTE_BF16, clips, 6)
+    Wb = R.to_torch(sd, round_bf16=True)
+    enc_rb = R.encoder_forward(torch.from_numpy(mel_ref), Wb, rd)
+    err = np.abs(enc_b - enc_rb.numpy())
+    assert err.max() < 0.15 and err.mean() < 0.012, (err.max(), err.mean())
+    xkv = R.cross_kv(enc_rb, Wb, rd)
+    cache = R.SelfCache.empty(rd.dec_layers)
+    logits = None
+    for t, lg in zip(prompt, step_logits_b):
+        logits = R.decoder_forward(torch.full((2, 1), t), cache, xkv, Wb, rd)[:, 0]
+        assert np.abs(lg - logits.numpy()).max() < 0.08
+    for i in range(min(len(t) for t in res_b.tokens)):
+        nxt = []
+        for b in range(2):
+            s = R.apply_rules(logits[b], res_b.tokens[b][:i], rules)
+            c = res_b.tokens[b][i]
+            assert float(s.max() - s[c]) < 0.15
+            nxt.append(c)
+        logits = R.decoder_forward(torch.tensor(nxt)[:, None], cache, xkv, Wb, rd)[:, 0]
