@@ -421,12 +421,11 @@ void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int v3_h(int q) { return (0x78 >> (q * 2)) & 3; }  // {0,2,3,1} packed two bits each
 
+template <int EPI>  // bit0 GELU, bit1 residual, bit2 row table (positions), bit3 head-split T output, bit4 f32 output
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BM = 256, BN = 256, BK = 32;
   constexpr int OP_BYTES = BM * BK * 2, STAGE_BYTES = 2 * OP_BYTES;  // 16K + 16K
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bool skip_epi = g.M < 0;
-  g.M = abs(g.M);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -443,7 +442,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
   const int m0 = tm * BM, n0 = tn * BN;
   const bf16_t* A = (const bf16_t*)g.A + (int64_t)blockIdx.z * g.batch_stride_a;
   const bf16_t* W = (const bf16_t*)g.W;
-
   // staging: one wave-instruction = 16 rows x 64 B; wave w moves rows (2w+p)*16 .. +15 of A and of W
   const int srow = lane >> 2, sslot = lane & 3;
   const bf16_t* a_src[2];
@@ -513,70 +511,78 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count
 #undef V3_STAGE
-  if (skip_epi) {  // keep the accumulators alive, store nothing
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][3];
-    if (t == 123.456f) g.epi.out_f32[0] = t;
-    return;
-  }
-  // ---- epilogue.  Every load (bias, positions, residual) is issued ahead of the stores it feeds: interleaved
-  // load -> store -> load chains serialise on memory latency (measured: 25-40 % of the kernel before this).
+  // ---- epilogue, specialised at compile time (EPI) so no integer division / dead branch survives for the
+  // common shapes; row offsets are computed once per row, column parts once per column group, and every load
+  // (bias, positions, residual) is issued ahead of the stores it feeds.  (The generic per-element epilogue cost
+  // 5 500 VALU instructions per thread: 25-40 % of the kernel.)
+  constexpr bool ACT = EPI & 1, RES = EPI & 2, ROWTAB = EPI & 4, HS = EPI & 8, OUTF = EPI & 16;
   const GemmEpi& e = g.epi;
   const int64_t zoff = (int64_t)blockIdx.z * e.batch_stride_c;
   const int nbase = n0 + wn * 64 + fq * 4;
   float4 bias4[4];
+  int64_t coloff[4];  // column part of the output index
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bias4[j] = e.bias ? *(const float4*)(e.bias + nbase + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < 4; ++j) {
+    const int n = nbase + j * 16;
+    bias4[j] = e.bias ? *(const float4*)(e.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HS) {
+      const int which = n / e.hs_d, nn = n - which * e.hs_d;
+      coloff[j] = (int64_t)which * e.hs_which + (int64_t)(nn >> 6) * e.hs_T * 64 + (nn & 63);
+    } else {
+      coloff[j] = n;
+    }
+  }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    float4 extra[4][4];  // residual (+ positions) for rows i = 4*half .. 4*half+3
+    float4 extra[4][4];
+    int64_t rowoff[4];  // row part of the output index (T output); f32 / residual use zoff + m * ldc
+    int64_t rowlin[4];
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const int m = min(m0 + wm * 128 + (half * 4 + ii) * 16 + fr, g.M - 1);
+      rowlin[ii] = zoff + (int64_t)m * e.ldc;
+      if (HS) {
+        const int bb = m / e.hs_T, tt = m - bb * e.hs_T;
+        rowoff[ii] = ((int64_t)bb * e.hs_H * e.hs_T + tt) * 64;
+      } else {
+        rowoff[ii] = rowlin[ii];
+      }
+      if (RES || ROWTAB) {
+        const int64_t tabrow = ROWTAB ? (int64_t)(m % e.rowmod) * e.ldc : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e.residual) r = *(const float4*)(e.residual + zoff + (int64_t)m * e.ldc + nbase + j * 16);
-        if (e.rowtab) {
-          const float4 t = *(const float4*)(e.rowtab + (int64_t)(m % e.rowmod) * e.ldc + nbase + j * 16);
-          r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        for (int j = 0; j < 4; ++j) {
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (RES) r = *(const float4*)(e.residual + rowlin[ii] + nbase + j * 16);
+          if (ROWTAB) {
+            const float4 t = *(const float4*)(e.rowtab + tabrow + nbase + j * 16);
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+          }
+          extra[ii][j] = r;
         }
-        extra[ii][j] = r;
       }
     }
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const int i = half * 4 + ii;
-      const int m = m0 + wm * 128 + i * 16 + fr;
-      if (m < g.M) {
+      if (m0 + wm * 128 + i * 16 + fr < g.M) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4 v = acc[i][j];
           v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
-          if (e.act == 1) {
+          if (ACT) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
           }
-          v[0] += extra[ii][j].x; v[1] += extra[ii][j].y; v[2] += extra[ii][j].z; v[3] += extra[ii][j].w;
-          const int n = nbase + j * 16;
-          int64_t idx = zoff + (int64_t)m * e.ldc + n;
-          if (e.out_f32) *(float4*)(e.out_f32 + idx) = make_float4(v[0], v[1], v[2], v[3]);
-          if (e.out_t) {
-            if (e.headsplit) {
-              const int which = n / e.hs_d, nn = n - which * e.hs_d;
-              const int hh = nn >> 6, jj = nn & 63;
-              const int bb = m / e.hs_T, tt = m - bb * e.hs_T;
-              idx = (int64_t)which * e.hs_which + (((int64_t)bb * e.hs_H + hh) * e.hs_T + tt) * 64 + jj;
-            }
+          if (RES || ROWTAB) { v[0] += extra[ii][j].x; v[1] += extra[ii][j].y; v[2] += extra[ii][j].z; v[3] += extra[ii][j].w; }
+          if (OUTF) {
+            *(float4*)(e.out_f32 + rowlin[ii] + nbase + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
             typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
             bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
             uint2 pk;
             pk.x = __builtin_bit_cast(uint32_t, lo);
             pk.y = __builtin_bit_cast(uint32_t, hi);
-            *(uint2*)((bf16_t*)e.out_t + idx) = pk;
+            *(uint2*)((bf16_t*)e.out_t + rowoff[ii] + coloff[j]) = pk;
           }
         }
       }
@@ -584,21 +590,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
   }
 }
 
-bool gemm_bf16_v3_ok(const GemmArgs& g) {
-  return g.N % 256 == 0 && g.K % 32 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.epi.ldc % 4 == 0 &&
-         ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
+// epilogue variants actually used by the encoder / cross-KV schedules; anything else takes the v2 kernel
+static int v3_epi_code(const GemmEpi& e) {
+  return (e.act == 1 ? 1 : 0) | (e.residual ? 2 : 0) | (e.rowtab ? 4 : 0) | (e.headsplit ? 8 : 0) | (e.out_f32 ? 16 : 0);
 }
-static int v3_skip_epi() { static int v = getenv("TTASR_V3_NOEPI") ? 1 : 0; return v; }
-void launch_gemm_bf16_v3(const GemmArgs& g_in, hipStream_t s) {
-  GemmArgs g = g_in;
-  if (v3_skip_epi()) g.M = -g.M;  // timing experiment: negative M = skip the epilogue
+bool gemm_bf16_v3_ok(const GemmArgs& g) {
+  const int code = v3_epi_code(g.epi);
+  const bool known = code == 0 || code == 1 || code == 18 || code == 21 || code == 8;
+  const bool one_out = (g.epi.out_f32 != nullptr) != (g.epi.out_t != nullptr);
+  return known && one_out && g.N % 256 == 0 && g.K % 32 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
+         g.epi.ldc % 4 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 &&
+         (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
+}
+template <int EPI>
+static void launch_v3(const GemmArgs& g, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     attr_done = true;
   }
-  const int tiles_m = (abs(g.M) + 255) / 256, tiles_n = g.N / 256;
-  hipLaunchKernelGGL(gemm_bf16_v3_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
+  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+  hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
+}
+void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s) {
+  switch (v3_epi_code(g.epi)) {
+    case 0: launch_v3<0>(g, s); break;    // bias -> T                 (qkv)
+    case 1: launch_v3<1>(g, s); break;    // bias + GELU -> T          (fc1, conv1)
+    case 18: launch_v3<18>(g, s); break;  // bias + residual -> f32    (out-proj, fc2)
+    case 21: launch_v3<21>(g, s); break;  // bias + GELU + positions -> f32 (conv2)
+    case 8: launch_v3<8>(g, s); break;    // bias -> head-split T      (cross-KV)
+    default: break;                       // excluded by gemm_bf16_v3_ok
+  }
 }
 
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
