@@ -13,6 +13,7 @@
 //   (4 consecutive keys of one d) comes from ds_read_b64_tr_b16 (guide T10).
 //   LDS swizzles: K chunk c of row k at c ^ ((k>>1)&7); V 64-byte half hf of row k at hf ^ ((k>>1)&1).
 #include "common.hpp"
+#include <type_traits>
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -99,9 +100,10 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   //   V tr-read (s, db, part): row = 16*s + 8*part + 4*hf + ((lane & 15) >> 2); byte = 64*db' + 32*((lane>>4)&1) + 8*(lane&3)
   const int vq = (lane & 15) >> 2, vp4 = lane & 3, vg = (lane >> 4) & 1;
 
-  for (int kt = 0; kt < n_tiles; ++kt) {
+  auto tile = [&](const int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     const int cur = kt & 1;
-    if (kt + 1 < n_tiles) FA_G_LOAD(kt + 1);
+    if (!LAST) FA_G_LOAD(kt + 1);
     const char* Kb = smem + cur * 16384;
     const char* Vb = Kb + 8192;
 
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
         s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb2], 0, 0, 0);
       }
     }
-    if (kt == n_tiles - 1) {  // mask keys past the end of the sequence
+    if (LAST) {  // mask keys past the end of the sequence (only the peeled last tile carries this code)
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
@@ -136,9 +138,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, s[1][j]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
     const float mb = -m_new * LOG2E;
-    m_run = m_new;
     float psum = 0.f;
     uint32_t pf[2][8];  // bf16-packed P^T: [kb2][2*s' + pair]
 #pragma unroll
@@ -150,11 +150,18 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
         psum += p0 + p1;
         pf[kb2][j >> 1] = pack_bf16(p0, p1);
       }
-    l_run = l_run * alpha + psum;
+    // rescale the running sums only when some query of this wave saw a new maximum (exact: alpha == 1 otherwise);
+    // after the first few tiles this is rare, and it keeps 32 multiplies + an exp out of the steady-state loop
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+      l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+        for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
+      m_run = m_new;
+    }
+    l_run += psum;
 
     // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 2 d-blocks ----
 #pragma unroll
@@ -178,9 +185,11 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
       }
     }
-    if (kt + 1 < n_tiles) FA_S_STORE(cur ^ 1);
+    if (!LAST) FA_S_STORE(cur ^ 1);
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < n_tiles; ++kt) tile(kt, std::false_type{});
+  tile(n_tiles - 1, std::true_type{});
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B ----
   const float l_tot = l_run + __shfl_xor(l_run, 32);
