@@ -123,6 +123,14 @@ int ttasr_generate(ttasr_ctx* ctx, int32_t B, const int32_t* prompt_host, const 
 int ttasr_generate_beam(ttasr_ctx* ctx, int32_t n_audio, int32_t beam, const int32_t* prompt_host, int32_t prompt_len,
                         const ttasr_gen_opts* opts, float patience, int32_t* out_tokens_host, int32_t* out_len_host,
                         float* out_sum_logprob_host, float* out_no_speech_host);
+/* Temperature sampling (the fallback ladder of faster-whisper's generate_with_fallback: temperatures 0.2 ... 1.0
+ * with best_of hypotheses).  n_audio clips x best_of independently sampled rows that share the clip's cross-KV;
+ * tokens are drawn from softmax(processed logits / temperature) with a counter-based generator keyed by
+ * (seed, row, position, token), so a run is reproducible; per clip the hypothesis with the highest
+ * sum_logprob / length is returned (EOT kept when emitted, as ttasr_generate). */
+int ttasr_generate_sample(ttasr_ctx* ctx, int32_t n_audio, int32_t best_of, const int32_t* prompt_host, int32_t prompt_len,
+                          const ttasr_gen_opts* opts, float temperature, uint32_t seed, int32_t* out_tokens_host,
+                          int32_t* out_len_host, float* out_sum_logprob_host, float* out_no_speech_host);
 /* Step-level access for parity tests: reset the self-attention cache, then feed one token per row per
  * call; logits_host (optional) receives raw float32 [B][vocab] for the position just fed. */
 int ttasr_decode_reset(ttasr_ctx* ctx, int32_t B);

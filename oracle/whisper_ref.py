@@ -469,3 +469,64 @@ def beam_decode(enc: torch.Tensor, prompt: Sequence[int], W: Dict[str, torch.Ten
         out_t.append([t for t in best if t != rules.eot])
         out_s.append(pool[best])
     return BeamResult(out_t, out_s, no_speech)
+
+
+# --------------------------------------------------------------------------------------------------
+# a11 (fallback ladder): temperature sampling.  faster-whisper's generate_with_fallback samples with
+# best_of hypotheses at temperatures 0.2 ... 1.0 when the greedy/beam result fails the compression-ratio or
+# log-prob thresholds (un-vendored; thresholds 2.4 / -1.0 / 0.6).  The draw is
+# Gumbel-max over processed_logits / T with a counter-based uniform u(seed, row, position, token) - the same
+# integer hash the HIP select kernel evaluates, so a sampled decode is reproducible on both sides.
+# --------------------------------------------------------------------------------------------------
+def _pcg_hash(x: np.ndarray) -> np.ndarray:
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x = (x * 747796405 + 2891336453) & 0xFFFFFFFF
+    w = (((x >> ((x >> 28) + 4)) ^ x) * 277803737) & 0xFFFFFFFF
+    return ((w >> 22) ^ w) & 0xFFFFFFFF
+
+
+def sample_gumbel(seed: int, row: int, position: int, n: int) -> np.ndarray:
+    key = _pcg_hash(np.uint64((seed & 0xFFFFFFFF) ^ int(_pcg_hash(np.uint64((row * 0x9E3779B9 + position) & 0xFFFFFFFF)))))
+    h = _pcg_hash((int(key) + np.arange(n, dtype=np.uint64)) & 0xFFFFFFFF)
+    u = (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0) + np.float32(0.5 / 16777216.0)
+    return -np.log(-np.log(u, dtype=np.float32), dtype=np.float32)
+
+
+def sample_decode(enc: torch.Tensor, prompt: Sequence[int], W: Dict[str, torch.Tensor], dims: Dims, rules: Rules,
+                  best_of: int, temperature: float, seed: int, max_new_tokens: int) -> GreedyResult:
+    """best_of independently sampled rows per clip; returns, per clip, the row with the best sum_logprob / length.
+    sum_logprob accumulates log_softmax of the processed (untempered) logits at the drawn token."""
+    A = enc.shape[0]
+    R = A * best_of
+    xkv_a = cross_kv(enc, W, dims)
+    xkv = [(k.repeat_interleave(best_of, dim=0), v.repeat_interleave(best_of, dim=0)) for k, v in xkv_a]
+    cache = SelfCache.empty(dims.dec_layers)
+    logits = None
+    for t in prompt:
+        logits = decoder_forward(torch.full((R, 1), t, dtype=torch.long), cache, xkv, W, dims)[:, -1]
+    sampled: List[List[int]] = [[] for _ in range(R)]
+    done = [False] * R
+    sum_lp = [0.0] * R
+    for _ in range(max_new_tokens):
+        position = cache.length - 1  # position of the token whose logits we hold
+        nxt = []
+        for r in range(R):
+            if done[r]:
+                nxt.append(rules.eot)
+                continue
+            s = apply_rules(logits[r], sampled[r], rules)
+            z = (s / np.float32(temperature)).numpy() + sample_gumbel(seed, r, position, s.shape[0])
+            t = int(np.argmax(z))
+            sum_lp[r] += float(torch.log_softmax(s, dim=-1)[t])
+            sampled[r].append(t)
+            done[r] = t == rules.eot
+            nxt.append(t)
+        if all(done) or cache.length >= dims.n_text_ctx:
+            break
+        logits = decoder_forward(torch.tensor(nxt, dtype=torch.long)[:, None], cache, xkv, W, dims)[:, -1]
+    toks, lps = [], []
+    for a in range(A):
+        rows = range(a * best_of, (a + 1) * best_of)
+        best = max(rows, key=lambda r: (sum_lp[r] / max(len(sampled[r]), 1), -r))
+        toks.append(sampled[best]); lps.append(sum_lp[best])
+    return GreedyResult(toks, lps, [0.0] * A)

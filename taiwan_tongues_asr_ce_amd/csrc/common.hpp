@@ -115,6 +115,8 @@ struct DecState {            // device-resident per-row search state
 struct RuleParams {
   int V, ldv, max_prompt, max_new;
   int eot, no_timestamps, timestamp_begin, no_speech, sot_index, timestamps, max_initial, suppress_eot;
+  float temperature;  // 0: argmax; > 0: sample from softmax(logits / temperature) by Gumbel-max with a counter hash
+  uint32_t seed;
 };
 template <typename T>
 void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);

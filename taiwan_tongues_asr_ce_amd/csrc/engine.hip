@@ -538,6 +538,7 @@ int upload_rules(ttasr_ctx* c, const ttasr_gen_opts* o, int max_prompt) {
   rp.eot = o->eot; rp.no_timestamps = o->no_timestamps; rp.timestamp_begin = o->timestamp_begin;
   rp.no_speech = o->no_speech; rp.sot_index = o->sot_index; rp.timestamps = o->timestamps;
   rp.max_initial = o->max_initial_timestamp_index; rp.suppress_eot = o->suppress_eot;
+  rp.temperature = 0.f; rp.seed = 0;
   if (rp.eot < 0 || rp.eot >= c->V || rp.timestamp_begin < 0 || rp.timestamp_begin > c->V)
     return fail(c, TTASR_E_INVALID, "special token ids outside vocabulary");
   return 0;
@@ -804,53 +805,99 @@ int ttasr_decode_step(ttasr_ctx* c, const int32_t* tokens, int32_t B, float* log
 }
 
 int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
-                   const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
-  TRY(check_ready(c, B));
-  if (!prompt || !prompt_len || !out_tokens || !out_len) return fail(c, TTASR_E_INVALID, "NULL argument");
-  if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
-  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
+                   const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns);
+
+namespace {
+// shared by ttasr_generate and ttasr_generate_sample: R rows, row r uses prompt (r / rows_per_clip)
+int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt, const int32_t* prompt_len, int max_prompt,
+                  const ttasr_gen_opts* o, float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp,
+                  float* out_ns) {
   int min_plen = 1 << 30, max_plen = 0;
-  for (int b = 0; b < B; ++b) {
-    if (prompt_len[b] < 1 || prompt_len[b] > max_prompt) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", b, prompt_len[b]);
-    min_plen = std::min(min_plen, prompt_len[b]); max_plen = std::max(max_plen, prompt_len[b]);
-    for (int j = 0; j < prompt_len[b]; ++j)
-      if (prompt[b * max_prompt + j] < 0 || prompt[b * max_prompt + j] >= c->V)
+  const int A = R / rows_per_clip;
+  for (int a = 0; a < A; ++a) {
+    if (prompt_len[a] < 1 || prompt_len[a] > max_prompt) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", a, prompt_len[a]);
+    min_plen = std::min(min_plen, prompt_len[a]); max_plen = std::max(max_plen, prompt_len[a]);
+    for (int j = 0; j < prompt_len[a]; ++j)
+      if (prompt[a * max_prompt + j] < 0 || prompt[a * max_prompt + j] >= c->V)
         return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
   }
   RuleParams old = c->rp;
   TRY(upload_rules(c, o, max_prompt));
+  c->rp.temperature = temperature; c->rp.seed = seed;
   if (memcmp(&old, &c->rp, sizeof old) != 0) drop_graphs(c);  // rule scalars are baked into the captured launches
-  TRY(reset_search(c, B));
+  TRY(reset_search(c, R));
   hipStream_t s = c->stream;
-  HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)B * max_prompt * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->plen_dev, prompt_len, B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev, (size_t)max_prompt * 4, 4, B, hipMemcpyDeviceToDevice, s));
+  std::vector<int32_t> pr((size_t)R * max_prompt, 0), pl(R);
+  for (int r = 0; r < R; ++r) {
+    const int a = r / rows_per_clip;
+    pl[r] = prompt_len[a];
+    memcpy(&pr[(size_t)r * max_prompt], &prompt[(size_t)a * max_prompt], (size_t)max_prompt * 4);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->prompt_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->plen_dev, pl.data(), R * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));  // pr / pl are stack temporaries
   c->st.prompt = c->prompt_dev; c->st.prompt_len = c->plen_dev;
-  c->B_dec = B;
+  c->B_dec = R;
+  c->kv_div = rows_per_clip;
+  struct Restore { ttasr_ctx* c; ~Restore() { c->kv_div = 1; } } restore{c};
   const int interval = std::max(1, o->check_interval);
   const int last_step = std::min(c->cfg.n_text_ctx, max_plen - 1 + o->max_new_tokens);  // exclusive
   hipEventRecord(c->ev[5], s);
   for (int step = 0; step < last_step; ++step) {
     const bool all_forced = step + 1 < min_plen;
     const bool need_logits = !all_forced || (o->no_speech >= 0 && step == o->sot_index);
-    TRY(step_graph(c, B, need_logits ? 0 : 2));
+    TRY(step_graph(c, R, need_logits ? 0 : 2));
     if (!o->suppress_eot && step + 1 >= min_plen && ((step + 1 - min_plen) % interval == interval - 1)) {
       HIPCHK(c, hipMemcpyAsync(c->pinned_i32, c->st.n_done, 4, hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
-      if (c->pinned_i32[0] >= B) break;
+      if (c->pinned_i32[0] >= R) break;
     }
   }
   hipEventRecord(c->ev[6], s);
-  std::vector<int32_t> all((size_t)B * c->rp.max_new);
-  HIPCHK(c, hipMemcpyAsync(out_tokens, c->st.out_tokens, (size_t)B * c->rp.max_new * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(out_len, c->st.n_sampled, B * 4, hipMemcpyDeviceToHost, s));
-  if (out_lp) HIPCHK(c, hipMemcpyAsync(out_lp, c->st.sum_logprob, B * 4, hipMemcpyDeviceToHost, s));
-  if (out_ns) HIPCHK(c, hipMemcpyAsync(out_ns, c->st.no_speech, B * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out_tokens, c->st.out_tokens, (size_t)R * c->rp.max_new * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemcpyAsync(out_len, c->st.n_sampled, R * 4, hipMemcpyDeviceToHost, s));
+  if (out_lp) HIPCHK(c, hipMemcpyAsync(out_lp, c->st.sum_logprob, R * 4, hipMemcpyDeviceToHost, s));
+  if (out_ns) HIPCHK(c, hipMemcpyAsync(out_ns, c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
-  // rows that hit the context limit without EOT keep what they sampled; clamp lengths to max_new
-  for (int b = 0; b < B; ++b) out_len[b] = std::min(out_len[b], c->rp.max_new);
+  for (int r = 0; r < R; ++r) out_len[r] = std::min(out_len[r], c->rp.max_new);
+  return TTASR_OK;
+}
+}  // namespace
+
+int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
+                   const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  TRY(check_ready(c, B));
+  if (!prompt || !prompt_len || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
+  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
+  return generate_rows(c, B, 1, prompt, prompt_len, max_prompt, o, 0.f, 0, out_tokens, out_len, out_lp, out_ns);
+}
+
+int ttasr_generate_sample(ttasr_ctx* c, int32_t A, int32_t best_of, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
+                          float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  if (!c) return TTASR_E_INVALID;
+  if (A < 1 || best_of < 1 || !(temperature > 0.f)) return fail(c, TTASR_E_INVALID, "n_audio, best_of >= 1 and temperature > 0 required");
+  const int R = A * best_of;
+  TRY(check_ready(c, R));
+  if (!prompt || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (A > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, A);
+  if (plen < 1 || plen > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "prompt_len %d", plen);
+  const int max_new = o->max_new_tokens;
+  std::vector<int32_t> toks((size_t)R * std::max(max_new, 1)), lens(R), plens(A, plen);
+  std::vector<float> lp(R), ns(R);
+  TRY(generate_rows(c, R, best_of, prompt, plens.data(), plen, o, temperature, seed, toks.data(), lens.data(), lp.data(), ns.data()));
+  for (int a = 0; a < A; ++a) {
+    int best = a * best_of;
+    for (int r = a * best_of; r < (a + 1) * best_of; ++r)
+      if (lp[r] / std::max(lens[r], 1) > lp[best] / std::max(lens[best], 1)) best = r;
+    memcpy(out_tokens + (size_t)a * max_new, &toks[(size_t)best * max_new], (size_t)max_new * 4);
+    out_len[a] = lens[best];
+    if (out_lp) out_lp[a] = lp[best];
+    if (out_ns) out_ns[a] = ns[a * best_of];
+  }
   return TTASR_OK;
 }
 

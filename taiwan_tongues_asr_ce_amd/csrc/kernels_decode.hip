@@ -64,6 +64,19 @@ __device__ __forceinline__ ArgMax am_wave(ArgMax a) {
   return a;
 }
 
+// Counter-based uniform for sampling: u(seed, row, position, token) in (0, 1); the CPU oracle evaluates the same
+// integer hash, so sampled decodes are reproducible and testable (oracle/whisper_ref.py sample_uniform).
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t x) {
+  x = x * 747796405u + 2891336453u;
+  const uint32_t w = ((x >> ((x >> 28u) + 4u)) ^ x) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ float gumbel_noise(uint32_t key, int i) {
+  const uint32_t h = pcg_hash(key + (uint32_t)i);
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f) + (0.5f / 16777216.0f);
+  return -logf(-logf(u));
+}
+
 // One workgroup (1024 threads) per row.  Pass 1: masked max/argmax of the text and timestamp ranges.
 // Pass 2: sum of exp over both ranges (f32).  Then the "timestamp mass > best text token" rule, the
 // choice, its log-probability, and the state update.  Reads the V-float row twice from L2.
@@ -132,8 +145,11 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   __syncthreads();
   if (lane == 0) { s_sum[0][wave] = sum_txt; s_sum[1][wave] = sum_ts; s_sum[2][wave] = sum_raw; }
   __syncthreads();
+  // decision by thread 0: forced-timestamp rule, log-normaliser, greedy choice
+  __shared__ float s_lse;
+  __shared__ int s_choice, s_live;
   if (tid == 0) {
-    s_i[2] = 0;
+    s_i[2] = 0; s_live = 0;
     float t0 = 0.f, t1 = 0.f, t2 = 0.f;
     for (int w = 0; w < 16; ++w) { t0 += s_sum[0][w]; t1 += s_sum[1][w]; t2 += s_sum[2][w]; }
     if (want_ns) st.no_speech[b] = __expf(row[p.no_speech] - mx_raw) / t2;
@@ -143,23 +159,45 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
       st.cur_tok[b] = p.eot;
     } else {
       // logsumexp(timestamps) > max(text)  <=>  log(t1) + mx_all > mx_txt   (common -lse cancels)
-      bool force_ts = p.timestamps && t1 > 0.f && (__logf(t1) + mx_all > mx_txt);
-      s_i[2] = force_ts;
-      int choice; float cv, lse;
-      if (force_ts) { choice = i_ts; cv = mx_ts; lse = __logf(t1) + mx_all; }
+      const bool force_ts = p.timestamps && t1 > 0.f && (__logf(t1) + mx_all > mx_txt);
+      s_i[2] = force_ts; s_live = 1;
+      if (force_ts) { s_choice = i_ts; s_lse = __logf(t1) + mx_all; }
       else {
-        bool pick_ts = mx_ts > mx_txt;  // ties go to the lower index, i.e. text
-        choice = pick_ts ? i_ts : i_txt; cv = pick_ts ? mx_ts : mx_txt; lse = __logf(t0 + t1) + mx_all;
+        const bool pick_ts = mx_ts > mx_txt;  // ties go to the lower index, i.e. text
+        s_choice = pick_ts ? i_ts : i_txt; s_lse = __logf(t0 + t1) + mx_all;
       }
-      st.cur_tok[b] = choice;
-      st.sum_logprob[b] += cv - lse;
-      if (r.n < p.max_new) st.out_tokens[b * p.max_new + r.n] = choice;
-      st.n_sampled[b] = r.n + 1;
-      st.pen_tok[b] = last;
-      st.last_tok[b] = choice;
-      if (choice >= tb && p.timestamps) st.last_ts[b] = choice;
-      if (choice == p.eot || r.n + 1 >= p.max_new) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
     }
+  }
+  __syncthreads();
+  if (p.temperature > 0.f && s_live) {  // pass 3: Gumbel-max sample over the allowed set
+    const bool force_ts = s_i[2] != 0;
+    const uint32_t key = pcg_hash(p.seed ^ pcg_hash((uint32_t)b * 0x9E3779B9u + (uint32_t)step));
+    ArgMax best{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < p.V; i += 1024) {
+      if (force_ts && i < tb) continue;
+      if (masked(i, r, p, st.mask)) continue;
+      best = am_merge(best, ArgMax{row[i] / p.temperature + gumbel_noise(key, i), i});
+    }
+    best = am_wave(best);
+    if (lane == 0) s_am[0][wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+      ArgMax x = lane < 16 ? s_am[0][lane] : ArgMax{-INFINITY, 0x7fffffff};
+      x = am_wave(x);
+      if (lane == 0) s_choice = x.i;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && s_live) {
+    const int choice = s_choice;
+    st.cur_tok[b] = choice;
+    st.sum_logprob[b] += row[choice] - s_lse;
+    if (r.n < p.max_new) st.out_tokens[b * p.max_new + r.n] = choice;
+    st.n_sampled[b] = r.n + 1;
+    st.pen_tok[b] = last;
+    st.last_tok[b] = choice;
+    if (choice >= tb && p.timestamps) st.last_ts[b] = choice;
+    if (choice == p.eot || r.n + 1 >= p.max_new) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
   }
   if (out_rows) {  // known-answer hook: the forced-timestamp branch also masks the text range
     __syncthreads();

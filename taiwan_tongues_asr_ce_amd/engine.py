@@ -172,6 +172,24 @@ class Engine:
                                                  lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_beam")
         return GenResult([toks[a, :lens[a]].tolist() for a in range(A)], lp, ns)
 
+    def generate_sample(self, prompts: Sequence[Sequence[int]], best_of: int, opts, temperature: float, seed: int = 0
+                        ) -> GenResult:
+        """Temperature sampling: best_of rows per clip (shared cross-KV), best average log-prob per clip returned."""
+        A = len(prompts)
+        plen = len(prompts[0])
+        assert all(len(p) == plen for p in prompts), "sampling needs equal-length prompts"
+        pr = np.asarray(prompts, dtype=np.int32).reshape(A, plen)
+        toks = np.zeros((A, opts.max_new_tokens), dtype=np.int32)
+        lens = np.zeros(A, dtype=np.int32)
+        lp = np.zeros(A, dtype=np.float32)
+        ns = np.zeros(A, dtype=np.float32)
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        self._check(self.lib.ttasr_generate_sample(self.h, A, best_of, pr.ctypes.data_as(i32p), plen, C.byref(opts),
+                                                   C.c_float(temperature), C.c_uint32(seed & 0xFFFFFFFF),
+                                                   toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                   lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_sample")
+        return GenResult([toks[a, :lens[a]].tolist() for a in range(A)], lp, ns)
+
     def decode_reset(self, B: int):
         self._check(self.lib.ttasr_decode_reset(self.h, B), "decode_reset")
 

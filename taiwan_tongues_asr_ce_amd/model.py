@@ -235,7 +235,9 @@ class WhisperModel:
                    condition_on_previous_text: bool = True, initial_prompt: Optional[str] = None,
                    without_timestamps: bool = False, max_new_tokens: Optional[int] = None,
                    no_speech_threshold: Optional[float] = 0.6, log_prob_threshold: Optional[float] = -1.0,
-                   max_initial_timestamp: float = 1.0, suppress_blank: bool = True, **kwargs
+                   max_initial_timestamp: float = 1.0, suppress_blank: bool = True,
+                   temperature: Union[float, Sequence[float]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0), best_of: int = 5,
+                   compression_ratio_threshold: Optional[float] = 2.4, **kwargs
                    ) -> Tuple[Iterator[Segment], TranscriptionInfo]:
         if isinstance(audio, str):
             audio = decode_audio(audio)
@@ -269,11 +271,14 @@ class WhisperModel:
                                                             initial_prompt=initial_prompt))
         return self._generate_segments(audio, language, task, condition_on_previous_text, initial_prompt,
                                        without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
-                                       max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0)), info
+                                       max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0),
+                                       tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),),
+                                       best_of, compression_ratio_threshold), info
 
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
                            no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,
-                           patience=1.0) -> Iterator[Segment]:
+                           patience=1.0, temperatures=(0.0,), best_of=5, compression_ratio_threshold=2.4
+                           ) -> Iterator[Segment]:
         eng, st = self.engine, self.special
         lang_tok = self._lang_token(language)
         n_total = int(np.ceil(len(audio) / HOP)) if len(audio) else 0
@@ -294,30 +299,50 @@ class WhisperModel:
             opts = eng.gen_opts(budget, timestamps=not without_timestamps, sot_index=sot_index,
                                 begin_suppress=[220, st.eot] if suppress_blank else [],
                                 max_initial_timestamp_index=int(round(max_initial_timestamp / 0.02)), check_interval=4)
-            res = eng.generate_beam([prompt], beam_size, opts, patience) if beam_size > 1 else eng.generate([prompt], opts)
-            toks = res.tokens[0]
-            n_tok = max(len(toks), 1)
-            avg_lp = float(res.sum_logprob[0]) / n_tok
-            ns = float(res.no_speech_prob[0])
+            # generate_with_fallback of faster-whisper: temperature 0 = beam/greedy, then sampled retries (best_of
+            # hypotheses) while the result is too repetitive (zlib compression ratio) or too unlikely (avg log-prob)
+            attempts = []
+            for temp in temperatures:
+                if temp <= 0.0:
+                    res = eng.generate_beam([prompt], beam_size, opts, patience) if beam_size > 1 else eng.generate([prompt], opts)
+                else:
+                    rows = max(1, min(best_of, self.max_batch))
+                    res = eng.generate_sample([prompt], rows, opts, temp, seed=(seek * 1000003 + int(temp * 1000)) & 0x7FFFFFFF)
+                toks = res.tokens[0]
+                n_tok = max(len(toks), 1)
+                avg_lp = float(res.sum_logprob[0]) / n_tok
+                ns = float(res.no_speech_prob[0])
+                text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
+                raw = text_all.encode("utf-8")
+                cr = (len(raw) / max(1, len(zlib.compress(raw)))) if raw else 0.0
+                attempts.append((temp, toks, avg_lp, ns, cr))
+                needs_fallback = (compression_ratio_threshold is not None and cr > compression_ratio_threshold) or \
+                                 (log_prob_threshold is not None and avg_lp < log_prob_threshold)
+                if no_speech_threshold is not None and ns > no_speech_threshold:
+                    needs_fallback = False  # silence: do not retry
+                if not needs_fallback:
+                    break
+            else:  # every temperature failed: keep the most likely attempt among the non-repetitive ones
+                ok = [a for a in attempts if compression_ratio_threshold is None or a[4] <= compression_ratio_threshold]
+                attempts.append(max(ok or attempts, key=lambda a: a[2]))
+            temp_used, toks, avg_lp, ns, cr = attempts[-1]
             time_offset = seek * HOP / SAMPLE_RATE
             if no_speech_threshold is not None and ns > no_speech_threshold and \
                     (log_prob_threshold is None or avg_lp < log_prob_threshold):
                 seek += win_frames  # silent window: skip it entirely
                 continue
             segs, advance = self._split_segments(toks, seek, win_frames, time_offset, without_timestamps)
-            text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
-            cr = (len(text_all.encode("utf-8")) / max(1, len(zlib.compress(text_all.encode("utf-8"))))) if text_all else 0.0
             limit = time_offset + win_frames * HOP / SAMPLE_RATE  # never report times past the audio that exists
             for (s0, s1, stoks) in segs:
                 text = self.tokenizer.decode([t for t in stoks if t < st.eot])
                 s0, s1 = min(s0, limit), min(s1, limit)
                 if s0 >= s1 or not text.strip():
                     continue
-                yield Segment(idx, seek, round(s0, 3), round(s1, 3), text, list(stoks), 0.0, avg_lp, cr, ns, None)
+                yield Segment(idx, seek, round(s0, 3), round(s1, 3), text, list(stoks), temp_used, avg_lp, cr, ns, None)
                 idx += 1
             prev.extend(t for t in toks if t < st.eot)
-            if not condition:
-                prompt_reset = len(prev)  # faster-whisper's prompt_reset_since: nothing carries over
+            if not condition or temp_used > 0.5:  # faster-whisper: prompt_reset_on_temperature = 0.5
+                prompt_reset = len(prev)  # prompt_reset_since: nothing carries over
             seek += min(advance, win_frames) if advance > 0 else win_frames
 
     # ------------------------------------------------------------------------------------------

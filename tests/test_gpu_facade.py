@@ -43,7 +43,7 @@ def test_transcribe_signature_of_the_reference_call_sites(model):
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
     # beam_size=5 as the reference passes it: first window == the oracle's beam search (limit 40 tokens for CPU time)
-    segments, _ = model.transcribe(audio, language="zh", beam_size=5, max_new_tokens=40)
+    segments, _ = model.transcribe(audio, language="zh", beam_size=5, max_new_tokens=40, temperature=0.0)
     segs = list(segments)
     ref = R.beam_decode(enc, [st.sot, st.lang_zh, st.transcribe], W, dims, rules, 5, 40)
     got = [t for s in segs if s.seek == 0 for t in s.tokens]  # first 30-s window
@@ -54,14 +54,14 @@ def test_transcribe_signature_of_the_reference_call_sites(model):
 def test_transcribe_errors_and_inputs(model, tmp_path):
     with pytest.raises(ValueError):
         model.transcribe(np.zeros((2, 16000), np.float32), language="zh", beam_size=1)
-    segs, info = model.transcribe(np.zeros(0, np.float32), language="zh", beam_size=1)
+    segs, info = model.transcribe(np.zeros(0, np.float32), language="zh", beam_size=1, temperature=0.0)
     assert list(segs) == [] and info.duration == 0.0
     import wave
     p = str(tmp_path / "x.wav")
     with wave.open(p, "wb") as w:
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
         w.writeframes((synth.noise_clip(2, 48000) * 32767).astype("<i2").tobytes())
-    segs, info = model.transcribe(p, beam_size=1)  # path input + language detection
+    segs, info = model.transcribe(p, beam_size=1, temperature=0.0)  # path input + language detection
     assert info.language in ("en", "zh") or len(info.language) <= 3
     assert 0.0 < info.language_probability <= 1.0 and abs(info.duration - 3.0) < 1e-3
     list(segs)
@@ -69,7 +69,7 @@ def test_transcribe_errors_and_inputs(model, tmp_path):
 
 def test_long_audio_windows_advance(model):
     audio = np.concatenate([synth.noise_clip(7), synth.noise_clip(8, 160000)])  # 40 s -> >= 2 windows
-    segs, info = model.transcribe(audio, language="zh", beam_size=1, without_timestamps=True)
+    segs, info = model.transcribe(audio, language="zh", beam_size=1, without_timestamps=True, temperature=0.0)
     segs = list(segs)
     assert len({s.seek for s in segs}) >= 2 and segs[-1].end <= 40.0 + 1e-6
 
@@ -91,3 +91,20 @@ def test_asr_adapter_result_dict():
     out = asyncio.run(asr.transcribe(client))
     assert out is None or set(out) == {"language", "language_probability", "final", "text", "duration", "words"}
     asr.warm_up()
+
+
+def test_fallback_ladder_runs_and_reports_temperature(model):
+    """Synthetic weights always fail the avg-logprob threshold, so the default ladder walks to a sampled result."""
+    audio = synth.noise_clip(11, 160000)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        segs, _ = model.transcribe(audio, language="zh", beam_size=1, max_new_tokens=24)
+        segs = list(segs)
+        greedy, _ = model.transcribe(audio, language="zh", beam_size=1, max_new_tokens=24, temperature=0.0)
+        greedy = list(greedy)
+    assert all(s.temperature == 0.0 for s in greedy)
+    assert segs and all(0.0 <= s.temperature <= 1.0 for s in segs)
+    # with a relaxed threshold the first attempt is accepted
+    ok, _ = model.transcribe(audio, language="zh", beam_size=1, max_new_tokens=24, log_prob_threshold=-100.0,
+                             compression_ratio_threshold=None)
+    assert [s.tokens for s in ok] == [s.tokens for s in greedy]
