@@ -205,3 +205,40 @@ def test_flash_attention_matches_simple_kernel(tiny_oracle):
     assert np.abs(a - b).max() < 0.05, np.abs(a - b).max()
     assert np.abs(a - b).mean() < 0.004, np.abs(a - b).mean()
     e.close()
+
+
+def test_ragged_prompts_and_lengths(eng_tiny_f32, tiny_oracle):
+    """Rows of one batch with different prompt lengths (previous-text conditioning) and different stop
+    points: each row must equal the oracle run on that clip alone."""
+    dims, W, clips, enc_ref = tiny_oracle
+    e = eng_tiny_f32
+    st = e.special
+    e.log_mel(clips, want_output=False)
+    e.encode(4)
+    prompts = [[st.sot, st.lang_zh, st.transcribe],
+               [st.sot_prev, 1000, 1001, 1002, st.sot, st.lang_zh, st.transcribe],
+               [st.sot, st.lang_zh, st.transcribe, st.no_timestamps][:3],
+               [st.sot_prev] + list(range(2000, 2012)) + [st.sot, st.lang_zh, st.transcribe]]
+    opts = e.gen_opts(10, True, check_interval=3, sot_index=0, no_speech=False)
+    res = e.generate(prompts, opts)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
+    for b, p in enumerate(prompts):
+        ref = R.greedy_decode(enc_ref[b:b + 1], p, W, dims, rules, 10)
+        assert res.tokens[b] == ref.tokens[0], b
+        assert abs(float(res.sum_logprob[b]) - ref.sum_logprob[0]) < 2e-2
+
+
+def test_api_misuse_is_an_error_not_a_crash(eng_tiny_f32):
+    from taiwan_tongues_asr_ce_amd.engine import TtasrError
+    e = eng_tiny_f32
+    st = e.special
+    with pytest.raises(TtasrError):
+        e.encode(5)  # > max_batch
+    with pytest.raises(TtasrError):
+        e.generate([[st.sot, e.dims.vocab + 5]], e.gen_opts(4, True))  # token outside the vocabulary
+    with pytest.raises(TtasrError):
+        e.generate([[st.sot]], e.gen_opts(0, True))  # max_new_tokens out of range
+    with pytest.raises(TtasrError):
+        e.generate_beam([[st.sot]] * 2, 5, e.gen_opts(4, True))  # rows > max_batch
+    assert e.log_mel([np.zeros(10, np.float32)]).shape == (1, 80, 3000)  # engine still healthy
