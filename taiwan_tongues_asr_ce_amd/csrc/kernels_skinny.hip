@@ -17,6 +17,7 @@
 // the decode chain).  NW waves split K inside the workgroup (LDS reduce); residual GEMMs additionally split K
 // across workgroups and add their partials to the f32 residual stream with float atomics.
 #include "common.hpp"
+#include <cstdlib>
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 __global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int row_offset) {
@@ -98,18 +99,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   if (b >= B) return;
   float vv[4] = {v.x, v.y, v.z, v.w};
   const float rr[4] = {eres.x, eres.y, eres.z, eres.w};
+  const int64_t idx0 = (int64_t)b * e.ldc + en;
+  if (en + 3 < N && ksplit == 1) {  // full 4-column cell: vector stores
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (e.act == 1) vv[j] = gelu_erf(vv[j]);
+      if (e.residual) vv[j] += rr[j];
+    }
+    if (e.out_f32) *(float4*)(e.out_f32 + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (e.out_t) {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(vv[0]) | ((uint32_t)f2bf(vv[1]) << 16);
+      pk.y = (uint32_t)f2bf(vv[2]) | ((uint32_t)f2bf(vv[3]) << 16);
+      *(uint2*)((bf16_t*)e.out_t + idx0) = pk;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = en + j;
     if (n < N) {
-      const int64_t idx = (int64_t)b * e.ldc + n;
+      const int64_t idx = idx0 + j;
       if (ksplit > 1) {
         atomicAdd(e.out_f32 + idx, vv[j]);  // accumulate into the f32 residual stream
       } else {
         float o = vv[j];
-        if (en + 3 >= N && e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
+        if (e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
         if (e.act == 1) o = gelu_erf(o);
-        if (e.residual) o += (en + 3 < N) ? rr[j] : e.residual[idx];
+        if (e.residual) o += e.residual[idx];
         if (e.out_f32) e.out_f32[idx] = o;
         if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(o);
       }
@@ -127,12 +144,16 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
   const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t;
   int nw = 4, ksplit = 1;
   if (can_split) {
-    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 5 && n_blocks * ksplit < 256) ksplit *= 2;
+    // 8 waves first (LDS reduce is cheaper than contended atomics), then split K across workgroups until a
+    // wave owns <= 10 k-steps; keep at least ~160 workgroups when the shape allows
+    if (ks_per >= 160 && ks_per % 8 == 0) nw = 8;  // long K (fc2): fewer, fatter workgroups = half the atomics
     while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 10) ksplit *= 2;
+    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 5 && n_blocks * ksplit < 160) ksplit *= 2;
   } else {
     while (nw < 16 && ks_per % (nw * 2) == 0 && ks_per / nw > 10) nw *= 2;
     if (nw < 8 && ks_per % 8 == 0 && ks_per / 8 >= 5 && n_blocks < 256) nw = 8;
   }
+  if (const char* f = getenv("TTASR_SKINNY_NW")) { if (!can_split) nw = atoi(f); }  // tuning experiments
   if (ks_per % (nw * ksplit) != 0) return false;
   dim3 grid(n_blocks, ksplit);
   if (nw == 16) hipLaunchKernelGGL(gemm_skinny_kernel<16>, grid, dim3(1024), 0, s, Wsh, x, B, N, K, ksplit, e);
