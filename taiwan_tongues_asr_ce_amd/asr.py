@@ -91,6 +91,9 @@ class ASRFactory:
 
     @staticmethod
     def create_asr_pipeline(type, **kwargs):
+        if type == "mi355x_whisper_batched":  # micro-batching backend for the WebSocket server (streaming.py)
+            from .streaming import BatchedWhisperASR
+            return BatchedWhisperASR(**kwargs)
         cls = ASRFactory._registry.get(type)
         if cls is None:
             raise ValueError(f"不支援的 ASR 管道類型: {type}。目前只支援 {sorted(ASRFactory._registry)}")

@@ -362,3 +362,29 @@ class WhisperModel:
                                 sot_index=sot_index)
             out.extend(eng.generate([prompt] * len(chunk), opts).tokens)
         return out
+
+    def transcribe_windows(self, clips: Sequence[np.ndarray], language: str = "zh", beam_size: int = 5,
+                           initial_prompt: Optional[str] = None, without_timestamps: bool = False,
+                           max_new_tokens: int = 224) -> List[Tuple[str, float]]:
+        """Batched single-window transcription for the streaming path: every clip (<= 30 s) is one row group of the
+        same engine pass (beam_size rows per clip sharing its cross-KV).  Returns (text, end_time_seconds) per clip."""
+        eng, st = self.engine, self.special
+        beam = max(1, min(beam_size, 7))
+        per_pass = max(1, self.max_batch // beam)
+        lang_tok = self._lang_token(language)
+        prev = self.tokenizer.encode(" " + initial_prompt.strip()) if initial_prompt else []
+        out: List[Tuple[str, float]] = []
+        for i in range(0, len(clips), per_pass):
+            chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + per_pass]]
+            eng.log_mel(chunk, want_output=False)
+            eng.encode(len(chunk))
+            prompt, sot_index = self._prompt(lang_tok, "transcribe", without_timestamps, prev)
+            opts = eng.gen_opts(min(max_new_tokens, self.dims.n_text_ctx - len(prompt)), timestamps=not without_timestamps,
+                                sot_index=sot_index)
+            res = eng.generate_beam([prompt] * len(chunk), beam, opts) if beam > 1 else eng.generate([prompt] * len(chunk), opts)
+            for c, toks in zip(chunk, res.tokens):
+                toks = [t for t in toks if t != st.eot]
+                ts = [t for t in toks if t >= st.timestamp_begin]
+                end = (ts[-1] - st.timestamp_begin) * 0.02 if ts else len(c) / SAMPLE_RATE
+                out.append((self.tokenizer.decode([t for t in toks if t < st.eot]), float(end)))
+        return out

@@ -1,0 +1,121 @@
+"""Streaming side of the hot path (BASELINE.json configs[4]).
+
+The reference's WebSocket server hands ~3-second utterances of up to 10 concurrent clients to ONE model and
+serialises them on the event loop: `transcribe` is a blocking call inside `async def`
+(faster_whisper_asr.py:170), so every client waits for every other client's full 30-s-padded decode.
+This module keeps the reference's trigger rule and result shape but coalesces concurrent requests into one
+batched engine pass (clips x beams = rows of one decode batch, cross-KV shared per clip) that runs in a worker
+thread, so the event loop stays free."""
+from __future__ import annotations
+
+import asyncio
+import logging
+import warnings
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .asr import MI355XWhisperASR, pcm16_bytes_to_float
+
+logger = logging.getLogger(__name__)
+
+
+def should_transcribe(scratch_bytes: int, vad_end_seconds: float, chunk_offset_seconds: float, sampling_rate: int = 16000,
+                      samples_width: int = 2) -> bool:
+    """The SilenceAtEndOfChunk trigger (buffering_strategies.py:118-126): transcribe when the last voiced
+    segment ends before (buffered seconds - offset), or when more than 2 s (after the offset) are buffered."""
+    last_segment_should_end_before = scratch_bytes / (sampling_rate * samples_width) - chunk_offset_seconds
+    return vad_end_seconds < last_segment_should_end_before or last_segment_should_end_before > 2
+
+
+def chunk_ready(buffer_bytes: int, chunk_length_seconds: float, sampling_rate: int = 16000, samples_width: int = 2) -> bool:
+    """buffering_strategies.py:66-71: a chunk is handed over once MORE than chunk_length seconds are buffered."""
+    return buffer_bytes > chunk_length_seconds * sampling_rate * samples_width
+
+
+class BatchedWhisperASR(MI355XWhisperASR):
+    """ASRInterface backend that micro-batches concurrent `transcribe(client)` calls.
+
+    max_clips * beam_size must fit the model's row budget (max_batch, <= 32 on the bf16 fast path)."""
+
+    def __init__(self, max_clips: int = 6, max_wait_ms: float = 5.0, **kwargs):
+        beam = int(kwargs.pop("beam_size", 5))
+        kwargs.setdefault("max_batch", max(8, max_clips * beam))
+        super().__init__(**kwargs)
+        self.default_transcribe_kwargs["beam_size"] = beam
+        self.max_clips = max(1, min(max_clips, self.asr_pipeline.max_batch // max(beam, 1)))
+        self.max_wait = max_wait_ms / 1000.0
+        self._queue: Optional[asyncio.Queue] = None
+        self._worker_task: Optional[asyncio.Task] = None
+        self.batches_run: List[int] = []  # sizes of the batches actually executed (observability / tests)
+
+    def _ensure_worker(self):
+        if self._queue is None:
+            self._queue = asyncio.Queue()
+        if self._worker_task is None or self._worker_task.done():
+            self._worker_task = asyncio.get_running_loop().create_task(self._worker())
+
+    async def _worker(self):
+        loop = asyncio.get_running_loop()
+        while True:
+            first = await self._queue.get()
+            batch = [first]
+            deadline = loop.time() + self.max_wait
+            while len(batch) < self.max_clips:
+                timeout = deadline - loop.time()
+                if timeout <= 0:
+                    break
+                try:
+                    batch.append(await asyncio.wait_for(self._queue.get(), timeout))
+                except asyncio.TimeoutError:
+                    break
+            audios = [a for a, _, _ in batch]
+            try:
+                results = await loop.run_in_executor(None, self._run_batch, audios)
+            except Exception as e:  # the reference logs and returns None per request
+                logger.error("batched transcribe failed: %s", e)
+                results = [None] * len(batch)
+            self.batches_run.append(len(batch))
+            for (_, last_start, fut), res in zip(batch, results):
+                if not fut.done():
+                    fut.set_result(self._result_dict(res, last_start))
+
+    def _run_batch(self, audios: Sequence[np.ndarray]) -> List[Optional[Tuple[str, float]]]:
+        kw = self.default_transcribe_kwargs
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs = self.asr_pipeline.transcribe_windows(audios, language="zh", beam_size=kw["beam_size"],
+                                                        initial_prompt=kw["initial_prompt"])
+        res: List[Optional[Tuple[str, float]]] = []
+        for audio, (text, end_time) in zip(audios, outs):
+            res.append((text, min(end_time, len(audio) / 16000.0)) if text.strip() else None)
+        return res
+
+    def _result_dict(self, res, last_start) -> Optional[Dict[str, Any]]:
+        if res is None:
+            return None
+        text, duration = res
+        if self.text_filter is not None:
+            filtered = self.text_filter(text)
+            text = text if filtered is None else filtered
+        return {"language": "zh", "language_probability": 1.0, "final": True, "text": text, "duration": duration, "words": []}
+
+    async def transcribe(self, client) -> Optional[Dict[str, Any]]:
+        try:
+            audio = pcm16_bytes_to_float(client.scratch_buffer)
+            self._ensure_worker()
+            fut = asyncio.get_running_loop().create_future()
+            await self._queue.put((audio, getattr(client, "last_start_time", 0) or 0, fut))
+            return await fut
+        except Exception as e:
+            logger.error("transcribe failed: %s", e)
+            return None
+
+    async def aclose(self):
+        if self._worker_task is not None:
+            self._worker_task.cancel()
+            try:
+                await self._worker_task
+            except (asyncio.CancelledError, Exception):
+                pass
+            self._worker_task = None

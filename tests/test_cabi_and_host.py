@@ -142,3 +142,17 @@ def test_synth_weights_are_order_independent():
     b = dict(synth.iter_weights(d))[specs[7][0]]
     np.testing.assert_array_equal(a, b)
     assert synth.noise_clip(3)[:4].tolist() == synth.noise_clip(3, 100)[:4].tolist()
+
+
+def test_streaming_trigger_rule_table():
+    """SilenceAtEndOfChunk (buffering_strategies.py:66-71,118-126) restated; the table is read off the reference
+    code: with SimpleVAD (one segment [0, duration]) the first clause never fires, so the trigger is 'more than
+    2 s after the offset', i.e. every second 1.5-s chunk at the default settings."""
+    from taiwan_tongues_asr_ce_amd.streaming import chunk_ready, should_transcribe
+    bps = 16000 * 2
+    assert not chunk_ready(int(1.5 * bps), 1.5) and chunk_ready(int(1.5 * bps) + 2, 1.5)
+    off = 0.1
+    for seconds, vad_end, want in [(1.5, 1.5, False), (2.0, 2.0, False), (2.1, 2.1, False), (2.11, 2.11, True),
+                                   (3.0, 3.0, True), (1.5, 1.0, True), (1.5, 1.39, True), (1.5, 1.41, False),
+                                   (0.5, 0.0, True), (0.05, 0.0, False)]:
+        assert should_transcribe(int(round(seconds * bps)), vad_end, off) == want, (seconds, vad_end)

@@ -108,3 +108,29 @@ def test_fallback_ladder_runs_and_reports_temperature(model):
     ok, _ = model.transcribe(audio, language="zh", beam_size=1, max_new_tokens=24, log_prob_threshold=-100.0,
                              compression_ratio_threshold=None)
     assert [s.tokens for s in ok] == [s.tokens for s in greedy]
+
+
+def test_batched_streaming_backend_coalesces_requests():
+    from taiwan_tongues_asr_ce_amd.asr import ASRFactory
+    asr = ASRFactory.create_asr_pipeline("mi355x_whisper_batched", model_size="synthetic:tiny", compute_type="float16",
+                                         max_clips=4, max_wait_ms=50.0, beam_size=2)
+    clients = [types.SimpleNamespace(scratch_buffer=bytearray((synth.noise_clip(20 + i, 48000) * 32767).astype("<i2").tobytes()),
+                                     client_id=f"c{i}", last_start_time=0.0) for i in range(6)]
+
+    async def run():
+        res = await asyncio.gather(*[asr.transcribe(c) for c in clients])
+        await asr.aclose()
+        return res
+
+    res = asyncio.run(run())
+    assert len(res) == 6 and sum(asr.batches_run) == 6 and max(asr.batches_run) > 1  # requests shared engine passes
+    for r in res:
+        assert r is None or (set(r) == {"language", "language_probability", "final", "text", "duration", "words"}
+                             and 0.0 <= r["duration"] <= 3.0 + 1e-6)
+    # same audio alone or inside a batch gives the same text
+    single = asr.asr_pipeline.transcribe_windows([pcm for pcm in [synth.noise_clip(20, 48000)]], beam_size=2,
+                                                 initial_prompt="繁體中文")
+    if res[0] is not None:
+        quant = (synth.noise_clip(20, 48000) * 32767).astype("<i2").astype(np.float32) / 32768.0
+        alone = asr.asr_pipeline.transcribe_windows([quant], beam_size=2, initial_prompt="繁體中文")
+        assert alone[0][0] == res[0]["text"]
