@@ -564,26 +564,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
       const int i = half * 4 + ii;
-      if (m0 + wm * 128 + i * 16 + fr < g.M) {
+      const bool row_ok = m0 + wm * 128 + i * 16 + fr < g.M;
+      uint2 pk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[i][j];
-          v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
-          if (ACT) {
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j];
+        v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
+        if (ACT) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
-          }
-          if (RES || ROWTAB) { v[0] += extra[ii][j].x; v[1] += extra[ii][j].y; v[2] += extra[ii][j].z; v[3] += extra[ii][j].w; }
-          if (OUTF) {
-            *(float4*)(e.out_f32 + rowlin[ii] + nbase + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-            bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
-            uint2 pk;
-            pk.x = __builtin_bit_cast(uint32_t, lo);
-            pk.y = __builtin_bit_cast(uint32_t, hi);
-            *(uint2*)((bf16_t*)e.out_t + rowoff[ii] + coloff[j]) = pk;
-          }
+          for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
+        }
+        if (RES || ROWTAB) { v[0] += extra[ii][j].x; v[1] += extra[ii][j].y; v[2] += extra[ii][j].z; v[3] += extra[ii][j].w; }
+        if (OUTF) {
+          if (row_ok) *(float4*)(e.out_f32 + rowlin[ii] + nbase + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+          bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
+          pk[j].x = __builtin_bit_cast(uint32_t, lo);
+          pk[j].y = __builtin_bit_cast(uint32_t, hi);
+        }
+      }
+      if (!OUTF) {
+        // Widen the bf16 stores (guide T21, 16-lane form): lanes l and l^16 hold columns 4q..4q+3 and 4q+4..4q+7 of
+        // the same row, so one v_permlane16_swap per dword over a pair of column groups (j, j+1) leaves the even
+        // 16-lane rows with 16 contiguous bytes of group j and the odd rows with 16 contiguous bytes of group j+1:
+        // 16 x 16-byte stores per lane instead of 32 x 8-byte (the store tail is issue-bound, not bandwidth-bound).
+        const bool odd = (fq & 1) != 0;
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+          auto sx = __builtin_amdgcn_permlane16_swap(pk[jp].x, pk[jp + 1].x, false, false);
+          auto sy = __builtin_amdgcn_permlane16_swap(pk[jp].y, pk[jp + 1].y, false, false);
+          // even row: {own group jp, partner's group jp}; odd row: {partner's group jp+1, own group jp+1}
+          const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+          const int jj = odd ? jp + 1 : jp;
+          if (row_ok) *(uint4*)((bf16_t*)e.out_t + rowoff[ii] + coloff[jj] - (odd ? 4 : 0)) = w;
         }
       }
     }
@@ -599,7 +613,7 @@ bool gemm_bf16_v3_ok(const GemmArgs& g) {
   const bool known = code == 0 || code == 1 || code == 18 || code == 21 || code == 8;
   const bool one_out = (g.epi.out_f32 != nullptr) != (g.epi.out_t != nullptr);
   return known && one_out && g.N % 256 == 0 && g.K % 32 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 &&
-         g.epi.ldc % 4 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 &&
+         g.epi.ldc % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 &&
          (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
 }
 template <int EPI>
