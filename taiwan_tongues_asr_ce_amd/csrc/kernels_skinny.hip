@@ -9,7 +9,7 @@
 // lane `lane`'s A operand of v_mfma_f32_32x32x16_bf16.  The batch rows are the B operand
 // (x[b = lane & 31][k...], L2-resident), so D = W_tile * x^T with rows = n, cols = b.
 //
-// What the measurements said (scratch/skinny_var.hip, fc1 shape, graph-replayed chain, boundary = 1.6 us):
+// What the measurements said (tools/microbench/skinny_var.hip, fc1 shape, graph-replayed chain, boundary = 1.6 us):
 //   weight stream alone 3.5 us; + MFMA/LDS-reduce/store 4.6-4.8 us; + batch-row loads at a 1:1 byte ratio
 //   5.0 us, at the 2:1 ratio of the 16x16x32 form 7.1 us; nontemporal weight loads +1.8 us.
 // Hence: 32x32x16 (1 KiB of x per 1 KiB of W), plain loads, and every load of the kernel (fragments, bias,
