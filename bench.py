@@ -89,8 +89,8 @@ def cpu_baseline(dims, n_new: int, budget_layers: int = 2, budget_steps: int = 6
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--new-tokens", type=int, default=128)
@@ -137,13 +137,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    phases = []
+    phases, per_step = [], []
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        toks = step()
+        ts = time.perf_counter()
+        toks = step()                       # generate() returns host tokens: the step ends synchronised
+        per_step.append(time.perf_counter() - ts)
         phases.append(eng.phase_ms())
     torch.cuda.synchronize()
     if world > 1:
@@ -154,6 +156,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert toks.shape == (world * B, args.new_tokens)
+
+    # PCIe-inclusive variant (never `value`): the same step with the PCM handed over as a pinned host buffer
+    host_ms = None
+    if rank == 0:
+        pcm_host = pcm.cpu().pin_memory()
+        hs = []
+        for _ in range(3):
+            ts = time.perf_counter()
+            eng.log_mel_host_ptr(pcm_host.data_ptr(), 480000, ns)
+            eng.encode(B)
+            eng.generate([prompt] * B, opts)
+            hs.append(time.perf_counter() - ts)
+        host_ms = float(np.median(hs)) * 1e3
+        del pcm_host
 
     if rank == 0:
         esz = 2 if args.compute == "bf16" else 4
@@ -186,7 +202,8 @@ def main():
                                    f"clips per GPU resident in HBM, log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
                        "clips_per_gpu": B, "new_tokens": args.new_tokens, "parallelism": f"dp{world}",
-                       "phase_ms": ph, "weight_load_s": round(t_load, 1)},
+                       "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
+                       "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
                      "frac": round(enc_tf / 2500.0, 4)},

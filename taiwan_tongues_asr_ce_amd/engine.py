@@ -96,6 +96,12 @@ class Engine:
         self._check(self.lib.ttasr_log_mel(self.h, C.c_void_p(dev_ptr), stride, ns.ctypes.data_as(C.POINTER(C.c_int64)),
                                            len(ns), 1, None), "log_mel(device)")
 
+    def log_mel_host_ptr(self, host_ptr: int, stride: int, n_samples: Sequence[int]):
+        """PCM in a caller-owned (ideally pinned) host buffer: the call includes the H2D copy."""
+        ns = np.asarray(n_samples, dtype=np.int64)
+        self._check(self.lib.ttasr_log_mel(self.h, C.c_void_p(host_ptr), stride, ns.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           len(ns), 0, None), "log_mel(host)")
+
     def set_mel(self, mel: np.ndarray):
         mel = np.ascontiguousarray(mel, dtype=np.float32)
         assert mel.shape[1:] == (self.dims.n_mels, self.dims.n_frames), mel.shape

@@ -1,0 +1,79 @@
+"""Folder tool (asr_core.py counterpart) on CPU with a model double — same approach as the reference's own
+test double (api/tests/test_file_asr.py:40-53): positional audio, the six kwargs, returns (segments, info)."""
+import json
+import os
+import wave
+
+import numpy as np
+import pytest
+
+from taiwan_tongues_asr_ce_amd import batch_cli
+
+
+class _Seg:
+    def __init__(self, text):
+        self.text = text
+
+
+class _Model:
+    def __init__(self, texts):
+        self.texts, self.calls = texts, []
+
+    def transcribe(self, audio, *, language, word_timestamps, vad_filter, beam_size, condition_on_previous_text, initial_prompt):
+        self.calls.append(dict(n=len(audio), language=language, word_timestamps=word_timestamps, vad_filter=vad_filter,
+                               beam_size=beam_size, cond=condition_on_previous_text, prompt=initial_prompt))
+        text = self.texts[len(self.calls) - 1]
+        if isinstance(text, Exception):
+            raise text
+        return (_Seg(t) for t in text), object()
+
+
+def _wav(path, n=1600):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.zeros(n, dtype="<i2")).tobytes())
+
+
+def test_list_and_transcript_discovery(tmp_path):
+    for n in ("b.wav", "a.WAV", "c.mp3", "d.txt", "e.ogg"):
+        (tmp_path / n).write_bytes(b"")
+    (tmp_path / "sub").mkdir(); (tmp_path / "sub" / "x.wav").write_bytes(b"")
+    assert [os.path.basename(f) for f in batch_cli.list_audio_files(str(tmp_path))] == ["a.WAV", "b.wav", "c.mp3"]
+    assert batch_cli.find_original_transcript(str(tmp_path / "b.wav")) is None
+    (tmp_path / "b_reference.txt").write_text("x", encoding="utf-8")
+    assert batch_cli.find_original_transcript(str(tmp_path / "b.wav")).endswith("b_reference.txt")
+    (tmp_path / "b.txt").write_text("x", encoding="utf-8")
+    assert batch_cli.find_original_transcript(str(tmp_path / "b.wav")).endswith("b.txt")     # plain name wins
+
+
+def test_process_audio_folder_contract(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    folder = tmp_path / "audio"; folder.mkdir()
+    for n in ("a.wav", "b.wav", "c.wav"):
+        _wav(folder / n)
+    (folder / "a.txt").write_text("今天天氣很好，我們去公園散步。\n", encoding="utf-8")
+    model = _Model([["今天天氣很好!，", "我去公園散步。"], RuntimeError("boom"), ["百分之十五 ＯＫ"]])
+    final = batch_cli.process_audio_folder(str(folder), model=model, log=lambda *_: None)
+    assert all(c == dict(n=1600, language="zh", word_timestamps=False, vad_filter=True, beam_size=5, cond=True, prompt="")
+               for c in model.calls) and len(model.calls) == 3
+    assert (folder / "a_asr.txt").read_text(encoding="utf-8") == "今天天氣很好我去公園散步"
+    assert (folder / "b_asr.txt").read_text(encoding="utf-8") == "檔案名稱: b.wav\n錯誤: boom\n"
+    assert (folder / "c_asr.txt").read_text(encoding="utf-8") == "15% ok"
+    on_disk = json.load(open(tmp_path / "asr_comparison_results.json", encoding="utf-8"))
+    assert on_disk == final
+    assert list(final) == ["summary", "detailed_results"]
+    assert list(final["summary"]) == ["total_files", "files_with_transcript", "files_with_cer", "average_cer",
+                                      "average_correct_rate", "total_substitutions", "total_deletions", "total_insertions"]
+    s = final["summary"]
+    assert (s["total_files"], s["files_with_transcript"], s["files_with_cer"]) == (3, 1, 1)
+    a, b, c = final["detailed_results"]
+    assert a["has_original_transcript"] and a["cer_result"]["deletions_count"] == 1 and a["cer_result"]["total_chars"] == 13
+    assert s["average_cer"] == pytest.approx(1 / 13) and s["total_deletions"] == 1
+    assert b == {"audio_file": "b.wav", "asr_result": None, "original_transcript": None, "cer_result": None,
+                 "has_original_transcript": False, "error": "boom"}
+    assert c["asr_result"] == "15% ok" and c["cer_result"] is None and "error" not in c
+
+
+def test_empty_folder_and_missing_folder(tmp_path, capsys):
+    assert batch_cli.process_audio_folder(str(tmp_path), model=_Model([]), log=lambda *_: None) is None
+    assert batch_cli.main([str(tmp_path / "nope")]) == 1
