@@ -19,7 +19,7 @@ from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Sequenc
 
 import numpy as np
 
-from . import synth
+from . import ct2, synth
 from .config import (COMPUTE_BF16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
                      WhisperDims)
 from .tokenizer import load_tokenizer
@@ -119,8 +119,7 @@ def _read_hf_dir(path: str) -> Tuple[WhisperDims, Iterable[Tuple[str, np.ndarray
                 if k != "proj_out.weight":
                     yield k, v.float().numpy()
         else:
-            raise FileNotFoundError(f"{path}: neither model.safetensors nor pytorch_model.bin "
-                                    "(CTranslate2 model.bin is not readable yet: SURVEY.md section 8f N1)")
+            raise FileNotFoundError(f"{path}: no model.bin (CTranslate2), model.safetensors or pytorch_model.bin")
     return dims, tensors()
 
 
@@ -135,7 +134,12 @@ class WhisperModel:
         self.model_size_or_path = model_size_or_path
         self.device = "cuda"
         self.compute_type = compute_type
-        if os.path.isdir(model_size_or_path):
+        self.ct2_config: dict = {}
+        if os.path.isdir(model_size_or_path) and ct2.is_ct2_dir(model_size_or_path):
+            # the deployed format (CTranslate2 model.bin; faster_whisper_asr.py:38) -- reader is unpinned, see ct2.py
+            dims, tensors, self.ct2_config = ct2.read_ct2_dir(model_size_or_path)
+            self.tokenizer = load_tokenizer(model_size_or_path, dims.vocab)
+        elif os.path.isdir(model_size_or_path):
             dims, tensors = _read_hf_dir(model_size_or_path)
             self.tokenizer = load_tokenizer(model_size_or_path, dims.vocab)
         elif model_size_or_path.startswith("synthetic:"):
@@ -145,7 +149,8 @@ class WhisperModel:
         else:
             raise FileNotFoundError(
                 f"{model_size_or_path!r} is not a local HF Whisper directory (no network for hub ids); use a directory "
-                "with config.json + model.safetensors, or 'synthetic:<preset>' for seeded random weights")
+                "with model.bin (CTranslate2) or config.json + model.safetensors (HF), or 'synthetic:<preset>' for seeded "
+                "random weights")
         self.dims = dims
         self.engine = Engine(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
         self.engine.load_weights(tensors)

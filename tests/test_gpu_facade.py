@@ -134,3 +134,35 @@ def test_batched_streaming_backend_coalesces_requests():
         quant = (synth.noise_clip(20, 48000) * 32767).astype("<i2").astype(np.float32) / 32768.0
         alone = asr.asr_pipeline.transcribe_windows([quant], beam_size=2, initial_prompt="繁體中文")
         assert alone[0][0] == res[0]["text"]
+
+
+def test_ct2_directory_loads_like_the_same_weights_in_memory(tmp_path):
+    """WhisperModel("models") on a CTranslate2 directory (fp16 model.bin, as `compute_type="float16"` deployments
+    ship) produces the tokens of the identical weights loaded directly, and the folder tool runs on top of it."""
+    import wave
+    from taiwan_tongues_asr_ce_amd import batch_cli, ct2
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    dims = PRESETS["micro"]
+    hf = {k: v.astype(np.float16).astype(np.float32) for k, v in synth.iter_weights(dims)}       # fp16-representable
+    variables, aliases = ct2.hf_to_ct2(hf.items(), dims, dtype=np.float16)
+    ct2.write_model_bin(str(tmp_path / "model.bin"), variables, aliases)
+    (tmp_path / "config.json").write_text("{}", encoding="utf-8")
+    m = WhisperModel(str(tmp_path), device="cuda", compute_type="float32", max_batch=2)
+    assert (m.dims.d_model, m.dims.enc_layers, m.dims.vocab) == (dims.d_model, dims.enc_layers, dims.vocab)
+    eng = m.engine
+    clip = synth.noise_clip(3)[: dims.n_frames * 160]
+    eng.log_mel([clip], want_output=False)
+    enc_ct2 = eng.encode(1, want_output=True)
+    W = R.to_torch(hf)
+    rd = R.Dims(**dims.as_dict())
+    enc_ref = R.encoder_forward(torch.from_numpy(R.log_mel(clip, dims.n_mels, n_samples=dims.n_frames * 160))[None], W, rd).numpy()
+    assert np.abs(enc_ct2 - enc_ref).max() < 1e-3
+    # folder tool end to end on the real engine
+    folder = tmp_path / "audio"; folder.mkdir()
+    with wave.open(str(folder / "a.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((clip * 32767).astype("<i2").tobytes())
+    (folder / "a.txt").write_text("測試", encoding="utf-8")
+    final = batch_cli.process_audio_folder(str(folder), model=m, output_json=str(tmp_path / "out.json"), log=lambda *_: None)
+    assert final["summary"]["total_files"] == 1 and "error" not in final["detailed_results"][0]
+    assert (folder / "a_asr.txt").exists()
