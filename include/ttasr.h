@@ -106,6 +106,13 @@ int ttasr_encode(ttasr_ctx* ctx, int32_t B, float* out_enc_host);
 int ttasr_set_encoder_output(ttasr_ctx* ctx, const float* enc_host, int32_t B); /* then builds cross K/V */
 int ttasr_get_cross_kv(ttasr_ctx* ctx, int32_t layer, int32_t which /*0 K, 1 V*/, int32_t B, float* out_host /*[B][H][T][64]*/);
 
+/* Short-window option (opt-in, a behavioural change versus Whisper's fixed 30-s training window, the
+ * same trade whisper.cpp's `audio_ctx` makes): subsequent log_mel / encode / generate calls use only the first n_ctx
+ * encoder positions (= 2*n_ctx mel frames = n_ctx*320 samples), n_ctx even, 4 <= n_ctx <= cfg.n_audio_ctx; 0 restores
+ * the model's window.  A 3-s utterance (n_ctx 150) then costs a tenth of the encoder flops and cross-KV bytes.
+ * Drops the resident mel / encoder state. */
+int ttasr_set_audio_ctx(ttasr_ctx* ctx, int32_t n_ctx);
+
 /* ---- a9-a10: decoder (ctranslate2 Whisper.generate) --------------------------------------------- */
 /* Greedy search.  prompt_host: [B][max_prompt] ids, prompt_len_host[b] of them valid (>=1).
  * out_tokens_host: [B][max_new_tokens] sampled ids (EOT included when emitted), out_len_host[b] count.

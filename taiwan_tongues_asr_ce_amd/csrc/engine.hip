@@ -1111,6 +1111,26 @@ int ttasr_sync(ttasr_ctx* c) {
   return TTASR_OK;
 }
 
+int ttasr_set_audio_ctx(ttasr_ctx* c, int32_t n_ctx) {
+  if (!c) return TTASR_E_INVALID;
+  if (n_ctx == 0) n_ctx = c->cfg.n_audio_ctx;
+  if (n_ctx < 4 || n_ctx > c->cfg.n_audio_ctx || (n_ctx & 1))
+    return fail(c, TTASR_E_INVALID, "audio context %d outside [4, %d] or odd", n_ctx, c->cfg.n_audio_ctx);
+  if (n_ctx == c->T) return TTASR_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // every buffer is sized for the model's full context; a shorter window only changes the strides inside them.
+  // Captured decode graphs hold the old strides, resident mel / encoder state is for the old window: drop both.
+  drop_graphs(c);
+  c->T = n_ctx; c->F = 2 * n_ctx; c->n_samples = c->F * 160;
+  c->B_mel = c->B_enc = c->B_dec = 0;
+  // the conv stem reads one zero row before each clip's first frame; those rows sit at clip stride (F + 2), so
+  // they move with the window: clear the padded images (conv1 only ever writes rows 1..F of each clip)
+  const size_t Fmax = 2 * (size_t)c->cfg.n_audio_ctx + 2;
+  HIPCHK(c, hipMemsetAsync(c->c1, 0, (size_t)c->maxB * Fmax * c->d * c->esz, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->mel_t, 0, (size_t)c->maxB * Fmax * c->M * c->esz, c->stream));
+  return TTASR_OK;
+}
+
 int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters, float* out_ms, double* out_bytes,
                        double* out_flops) {
   TRY(check_ready(c, B));

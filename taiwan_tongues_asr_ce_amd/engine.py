@@ -49,6 +49,7 @@ class Engine:
             raise TtasrError(f"ttasr_create failed ({rc}): {self.lib.ttasr_last_error(None).decode()}")
         self.h = h
         self.special = SpecialTokens.for_vocab(dims.vocab)
+        self.audio_ctx = dims.n_audio_ctx
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int, what: str):
@@ -75,9 +76,16 @@ class Engine:
         self._check(self.lib.ttasr_finalize_weights(self.h), "finalize_weights")
 
     # -- a5 ------------------------------------------------------------------------------------
+    def set_audio_ctx(self, n_ctx: int = 0):
+        """Opt-in short window (ttasr_set_audio_ctx): the next log_mel/encode/generate use n_ctx encoder positions
+        (n_ctx * 320 samples); 0 restores the model's 30-s window."""
+        n = int(n_ctx) or self.dims.n_audio_ctx
+        self._check(self.lib.ttasr_set_audio_ctx(self.h, n), "set_audio_ctx")
+        self.audio_ctx = n
+
     def log_mel(self, clips: Sequence[np.ndarray], want_output: bool = True) -> Optional[np.ndarray]:
         B = len(clips)
-        n_win = self.dims.n_frames * 160
+        n_win = 2 * self.audio_ctx * 160
         stride = max(1, min(n_win, max((len(c) for c in clips), default=1)))
         pcm = np.zeros((B, stride), dtype=np.float32)
         ns = np.zeros(B, dtype=np.int64)
@@ -85,7 +93,7 @@ class Engine:
             n = min(len(c), stride)
             pcm[b, :n] = np.asarray(c[:n], dtype=np.float32)
             ns[b] = n
-        out = np.empty((B, self.dims.n_mels, self.dims.n_frames), dtype=np.float32) if want_output else None
+        out = np.empty((B, self.dims.n_mels, 2 * self.audio_ctx), dtype=np.float32) if want_output else None
         self._check(self.lib.ttasr_log_mel(self.h, _ptr(pcm), stride, ns.ctypes.data_as(C.POINTER(C.c_int64)), B, 0,
                                            _ptr(out) if want_output else None), "log_mel")
         return out
@@ -104,12 +112,12 @@ class Engine:
 
     def set_mel(self, mel: np.ndarray):
         mel = np.ascontiguousarray(mel, dtype=np.float32)
-        assert mel.shape[1:] == (self.dims.n_mels, self.dims.n_frames), mel.shape
+        assert mel.shape[1:] == (self.dims.n_mels, 2 * self.audio_ctx), mel.shape
         self._check(self.lib.ttasr_set_mel(self.h, _ptr(mel), mel.shape[0]), "set_mel")
 
     # -- a6..a8 --------------------------------------------------------------------------------
     def encode(self, B: int, want_output: bool = False) -> Optional[np.ndarray]:
-        out = np.empty((B, self.dims.n_audio_ctx, self.dims.d_model), dtype=np.float32) if want_output else None
+        out = np.empty((B, self.audio_ctx, self.dims.d_model), dtype=np.float32) if want_output else None
         self._check(self.lib.ttasr_encode(self.h, B, _ptr(out) if want_output else None), "encode")
         return out
 
@@ -118,7 +126,7 @@ class Engine:
         self._check(self.lib.ttasr_set_encoder_output(self.h, _ptr(enc), enc.shape[0]), "set_encoder_output")
 
     def cross_kv(self, layer: int, which: int, B: int) -> np.ndarray:
-        out = np.empty((B, self.dims.n_heads, self.dims.n_audio_ctx, 64), dtype=np.float32)
+        out = np.empty((B, self.dims.n_heads, self.audio_ctx, 64), dtype=np.float32)
         self._check(self.lib.ttasr_get_cross_kv(self.h, layer, which, B, _ptr(out)), "get_cross_kv")
         return out
 

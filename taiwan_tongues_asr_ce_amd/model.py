@@ -170,6 +170,7 @@ class WhisperModel:
     def detect_language(self, audio: np.ndarray) -> Tuple[str, float, List[Tuple[str, float]]]:
         """Language = argmax over the language tokens of the logits after <|startoftranscript|>."""
         eng, st = self.engine, self.special
+        eng.set_audio_ctx(0)
         eng.log_mel([audio[: self.n_window]], want_output=False)
         eng.encode(1)
         eng.decode_reset(1)
@@ -297,6 +298,7 @@ class WhisperModel:
         while seek < n_total:
             chunk = audio[seek * HOP: seek * HOP + self.n_window]
             win_frames = min(n_win, n_total - seek)
+            eng.set_audio_ctx(0)
             eng.log_mel([chunk], want_output=False)
             eng.encode(1)
             prompt, sot_index = self._prompt(lang_tok, task, without_timestamps, prev[prompt_reset:])
@@ -360,6 +362,7 @@ class WhisperModel:
         lang_tok = self._lang_token(language)
         for i in range(0, len(clips), self.max_batch):
             chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + self.max_batch]]
+            eng.set_audio_ctx(0)
             eng.log_mel(chunk, want_output=False)
             eng.encode(len(chunk))
             prompt, sot_index = self._prompt(lang_tok, task, without_timestamps, [])
@@ -368,11 +371,26 @@ class WhisperModel:
             out.extend(eng.generate([prompt] * len(chunk), opts).tokens)
         return out
 
+    def _pick_audio_ctx(self, audio_ctx: Union[None, int, str], longest_samples: int) -> int:
+        full = self.dims.n_audio_ctx
+        if audio_ctx is None:
+            return full
+        if audio_ctx == "auto":
+            need = -(-longest_samples // 320) + 25
+            return min(full, max(50, -(-need // 50) * 50))
+        n = int(audio_ctx)
+        if n < 4 or n > full or n % 2:
+            raise ValueError(f"audio_ctx={audio_ctx!r}: need an even value in [4, {full}], 'auto' or None")
+        return n
+
     def transcribe_windows(self, clips: Sequence[np.ndarray], language: str = "zh", beam_size: int = 5,
                            initial_prompt: Optional[str] = None, without_timestamps: bool = False,
-                           max_new_tokens: int = 224) -> List[Tuple[str, float]]:
+                           max_new_tokens: int = 224, audio_ctx: Union[None, int, str] = None) -> List[Tuple[str, float]]:
         """Batched single-window transcription for the streaming path: every clip (<= 30 s) is one row group of the
-        same engine pass (beam_size rows per clip sharing its cross-KV).  Returns (text, end_time_seconds) per clip."""
+        same engine pass (beam_size rows per clip sharing its cross-KV).  Returns (text, end_time_seconds) per clip.
+
+        audio_ctx (opt-in, SURVEY 8f N2): encode only that many positions (20 ms each) instead of the 30-s window;
+        "auto" = the longest clip of the pass + 0.5 s, rounded up to a multiple of 50.  None keeps Whisper's window."""
         eng, st = self.engine, self.special
         beam = max(1, min(beam_size, 7))
         per_pass = max(1, self.max_batch // beam)
@@ -381,6 +399,7 @@ class WhisperModel:
         out: List[Tuple[str, float]] = []
         for i in range(0, len(clips), per_pass):
             chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + per_pass]]
+            eng.set_audio_ctx(self._pick_audio_ctx(audio_ctx, max(len(c) for c in chunk)))
             eng.log_mel(chunk, want_output=False)
             eng.encode(len(chunk))
             prompt, sot_index = self._prompt(lang_tok, "transcribe", without_timestamps, prev)

@@ -36,10 +36,14 @@ def chunk_ready(buffer_bytes: int, chunk_length_seconds: float, sampling_rate: i
 class BatchedWhisperASR(MI355XWhisperASR):
     """ASRInterface backend that micro-batches concurrent `transcribe(client)` calls.
 
-    max_clips * beam_size must fit the model's row budget (max_batch, <= 32 on the bf16 fast path)."""
+    max_clips * beam_size must fit the model's row budget (max_batch, <= 32 on the bf16 fast path).
+    `audio_ctx="auto"` additionally encodes only as many positions as the longest utterance of a batch needs
+    (a 3-s utterance: 200 of 1500 positions), which is a behavioural change and therefore opt-in."""
 
-    def __init__(self, max_clips: int = 6, max_wait_ms: float = 5.0, **kwargs):
+    def __init__(self, max_clips: int = 6, max_wait_ms: float = 5.0, audio_ctx=None, max_new_tokens: int = 224, **kwargs):
         beam = int(kwargs.pop("beam_size", 5))
+        self.audio_ctx = audio_ctx            # None = Whisper's 30-s window; "auto"/int = opt-in short window (N2)
+        self.max_new_tokens = max_new_tokens
         kwargs.setdefault("max_batch", max(8, max_clips * beam))
         super().__init__(**kwargs)
         self.default_transcribe_kwargs["beam_size"] = beam
@@ -85,7 +89,8 @@ class BatchedWhisperASR(MI355XWhisperASR):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             outs = self.asr_pipeline.transcribe_windows(audios, language="zh", beam_size=kw["beam_size"],
-                                                        initial_prompt=kw["initial_prompt"])
+                                                        initial_prompt=kw["initial_prompt"], audio_ctx=self.audio_ctx,
+                                                        max_new_tokens=self.max_new_tokens)
         res: List[Optional[Tuple[str, float]]] = []
         for audio, (text, end_time) in zip(audios, outs):
             res.append((text, min(end_time, len(audio) / 16000.0)) if text.strip() else None)

@@ -242,3 +242,52 @@ def test_api_misuse_is_an_error_not_a_crash(eng_tiny_f32):
     with pytest.raises(TtasrError):
         e.generate_beam([[st.sot]] * 2, 5, e.gen_opts(4, True))  # rows > max_batch
     assert e.log_mel([np.zeros(10, np.float32)]).shape == (1, 80, 3000)  # engine still healthy
+
+
+# ---------------------------------------------------------------- N2: opt-in short audio window
+@pytest.mark.parametrize("compute,enc_tol", [(COMPUTE_F32, 1e-3), (COMPUTE_BF16, 0.08)])
+def test_short_audio_ctx_matches_oracle_on_the_truncated_window(compute, enc_tol):
+    """ttasr_set_audio_ctx(n): mel / encoder / cross-KV / decode over the first n positions only == the oracle run
+    on the clip trimmed to n*320 samples with the first n position embeddings; switching back restores the full
+    window (captured decode graphs must not survive the switch)."""
+    from taiwan_tongues_asr_ce_amd.engine import TtasrError, default_suppress
+    name = "tiny"
+    dims, pd = _dims(name), PRESETS[name]
+    e = _engine(name, compute, 3)
+    st = e.special
+    W = R.to_torch(synth.state_dict(pd), round_bf16=compute == COMPUTE_BF16)
+    clips = [synth.noise_clip(0)[:48000], synth.tonal_clip(1)[:40000], synth.burst_clip(2)[:64000]]
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=False)
+    opts = e.gen_opts(12, False)
+
+    def run(n_ctx):
+        e.set_audio_ctx(n_ctx)
+        n = n_ctx or pd.n_audio_ctx
+        mel = e.log_mel(clips)
+        assert mel.shape == (3, pd.n_mels, 2 * n)
+        want_mel = np.stack([R.log_mel(c, pd.n_mels, n_samples=n * 320) for c in clips])
+        np.testing.assert_allclose(mel, want_mel, atol=2e-4, rtol=0)
+        enc = e.encode(3, want_output=True)
+        assert enc.shape == (3, n, pd.d_model)
+        enc_ref = R.encoder_forward(torch.from_numpy(want_mel), W, dims)
+        assert np.abs(enc - enc_ref.numpy()).max() < enc_tol
+        kv = e.cross_kv(pd.dec_layers - 1, 1, 3)
+        ref_kv = R.cross_kv(enc_ref, W, dims)[pd.dec_layers - 1][1].numpy()
+        assert kv.shape == ref_kv.shape and np.abs(kv - ref_kv).max() < enc_tol * 2
+        res = e.generate([prompt] * 3, opts)
+        if compute == COMPUTE_F32:
+            ref = R.greedy_decode(enc_ref, prompt, W, dims, rules, 12)
+            assert res.tokens == ref.tokens
+        return res.tokens
+
+    short = run(200)          # 4-s window
+    full = run(0)             # back to 30 s: different strides, graphs re-captured
+    again = run(200)
+    assert again == short
+    assert all(len(t) > 0 for t in full)
+    for bad in (3, 151, 1502):
+        with pytest.raises(TtasrError):
+            e.set_audio_ctx(bad)
+    e.close()
