@@ -121,6 +121,12 @@ struct RuleParams {
 template <typename T>
 void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
 template <typename T>
+void launch_embed_prefill(const int32_t* prompt, int max_prompt, int rows_per_prompt, int n_seq, int npos, const T* emb, const T* pos,
+                          float* x, int d, hipStream_t s);
+template <typename T>
+void launch_self_attn_prefill(const T* qkv /*[n_seq*npos][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
+                              int64_t pool_layer_off, int identity_pages, T* out, int n_seq, int npos, int H, hipStream_t s);
+template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
                              int64_t pool_layer_off, int identity_pages, int row0, const int32_t* step, T* out /*[B][d]*/, int B, int H,
                              hipStream_t s);

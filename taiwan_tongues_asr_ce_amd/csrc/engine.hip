@@ -90,6 +90,7 @@ struct ttasr_ctx {
   int max_new_alloc = 0, max_prompt_alloc = 0;
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
+  bool no_prefill = false;  // TTASR_NO_PREFILL: feed prompts token by token (A/B testing)
   hipEvent_t ev[8]{};
   float phase_ms[4]{0, 0, 0, 0};
 
@@ -464,6 +465,47 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
   }
 }
 
+// Batched prompt prefill: positions 0..npos-1 of n_seq sequences in ONE pass (rows [sequence][position]) instead of
+// npos token-by-token steps.  Only the self-attention K/V of those positions has to survive (no logits: every one of
+// these positions is followed by another forced prompt token), so the pass borrows the encoder's activation
+// workspaces, which are idle once the cross-KV is built.  Sequence s attends to the cross-KV of clip s / seq_per_clip.
+// GEMMs go through the encoder dispatch (M = n_seq * npos rows; 256x256 MFMA tiles once M >= 256).
+template <typename T>
+void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip) {
+  const int d = c->d, ffn = c->ffn, n = n_seq * npos;
+  hipStream_t s = c->cur = c->stream;
+  float* x = c->x;
+  void *h = c->h, *qkv = c->qkv, *att = c->att, *mid = c->mid;
+  launch_embed_prefill<T>(c->prompt_dev, c->rp.max_prompt, 1, n_seq, npos, (const T*)c->emb, (const T*)c->dpos, x, d, s);
+  for (int l = 0; l < c->cfg.dec_layers; ++l) {
+    const DecLayerW& L = c->dec[l];
+    launch_layernorm<T>(x, L.ln1g, L.ln1b, (T*)h, n, d, s);
+    { GemmArgs g = lin_args<T>(h, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = qkv; gemm<T>(c, g); }
+    launch_self_attn_prefill<T>((const T*)qkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
+                                c->identity_pages, (T*)att, n_seq, npos, c->H, s);
+    { GemmArgs g = lin_args<T>(att, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+    launch_layernorm<T>(x, L.ln2g, L.ln2b, (T*)h, n, d, s);
+    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = qkv; gemm<T>(c, g); }  // q reuses the qkv buffer
+    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
+    launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s);
+    { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+    launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);
+    { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(mid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+  }
+}
+
+// How many leading prompt positions can be prefilled: every row must still have a forced token after them, the
+// no-speech probability needs real logits at the <|startoftranscript|> position, and the rows must fit the
+// borrowed encoder workspaces.  Below 2 positions the pass does not pay.
+int prefill_positions(const ttasr_ctx* c, int min_plen, const ttasr_gen_opts* o) {
+  if (c->no_prefill) return 0;
+  int p = min_plen - 1;
+  if (o->no_speech >= 0) p = std::min(p, o->sot_index);
+  p = std::min(p, c->cfg.n_audio_ctx);
+  return p >= 2 ? p : 0;
+}
+
 // A decode step is a chain of ~350 launches of 4-8 us each, every one paying a launch boundary and a memory
 // round trip while most of the chip idles; only cross-attention is bandwidth-bound.  For B >= 32 the batch is
 // therefore split into two half-batches whose chains run CONCURRENTLY (two streams forked and joined inside the
@@ -598,6 +640,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->n_samples = c->F * 160;
   c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
+  c->no_prefill = getenv("TTASR_NO_PREFILL") != nullptr;
   if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
@@ -844,7 +887,14 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   const int interval = std::max(1, o->check_interval);
   const int last_step = std::min(c->cfg.n_text_ctx, max_plen - 1 + o->max_new_tokens);  // exclusive
   hipEventRecord(c->ev[5], s);
-  for (int step = 0; step < last_step; ++step) {
+  const int pre = prefill_positions(c, min_plen, o);
+  if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
+    if (c->bf16) run_prefill<bf16_t>(c, R, pre, rows_per_clip); else run_prefill<float>(c, R, pre, rows_per_clip);
+    c->pinned_i32[1] = pre;
+    HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev + pre, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
+  }
+  for (int step = pre; step < last_step; ++step) {
     const bool all_forced = step + 1 < min_plen;
     const bool need_logits = !all_forced || (o->no_speech >= 0 && step == o->sot_index);
     TRY(step_graph(c, R, need_logits ? 0 : 2));
@@ -940,8 +990,31 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
   rebuild_free(-1);
   for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen];
   hipEventRecord(c->ev[5], s);
+  // Batched prompt prefill: the beam rows of a clip share one prompt, so its positions are computed ONCE per clip
+  // into pages that all `beam` page tables then reference (the copy-on-write below splits the last, partially
+  // filled page on the first private write).
+  const int pre = prefill_positions(c, plen, o);
+  if (pre > 0) {
+    const int n_pg = (pre + 15) / 16;
+    std::vector<int32_t> ptab((size_t)A * pps, 0);
+    for (int a = 0; a < A; ++a)
+      for (int q = 0; q < n_pg; ++q) {
+        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
+        const int32_t pg = free_pages.back(); free_pages.pop_back();
+        for (int b = 0; b < beam; ++b) tbl[(size_t)(a * beam + b) * pps + q] = pg;
+        ptab[(size_t)a * pps + q] = pg;
+      }
+    HIPCHK(c, hipMemcpyAsync(c->page_table, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * plen * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));  // ptab is a stack temporary
+    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1); else run_prefill<float>(c, A, pre, 1);
+    c->pinned_i32[1] = pre;
+    HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
+    rebuild_free(n_pg - 1);
+    for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pre];
+  }
   bool stop = false;
-  for (int pos = 0; pos < c->cfg.n_text_ctx && !stop; ++pos) {
+  for (int pos = pre; pos < c->cfg.n_text_ctx && !stop; ++pos) {
     // 1. the page this step writes must exist and be private to the row (copy-on-write after a re-index)
     const int j = pos / 16;
     pairs.clear();

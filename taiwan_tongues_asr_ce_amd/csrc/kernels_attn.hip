@@ -112,33 +112,41 @@ constexpr int PAGE = 16;
 // state (m, l, acc[VEC]) for its row slot, K and V rows of an iteration are requested together, and the
 // 8 x 4 slots are merged once at the end (flash-decoding inside the workgroup).  With identity_pages the
 // page index is computed (b * pages_per_seq + t / 16) instead of loaded, which removes a dependent load.
-template <typename T>
+//
+// MODE 0 is the decode step described above.  MODES 1 and 2 are the two launches of the batched prompt PREFILL:
+// grid row b is position (b % npos) of sequence (b / npos); launch 1 only appends every position's k,v to the
+// pool, launch 2 attends causally (keys 0..pos-1 from the pool, its own from registers) without appending - two
+// launches because a position reads keys that other workgroups of the first launch write.
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
                                                                const int32_t* __restrict__ page_table, int pages_per_seq,
                                                                int identity_pages, int row0,
-                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H) {
+                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H,
+                                                               int npos) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
   __shared__ float part[4][64];
   __shared__ float red[4][2];
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int d = H * 64, pos = *step;
+  const int d = H * 64, pos = MODE == 0 ? *step : b % npos;
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float q[VEC], kn[VEC], vn[VEC];
   RowVec<T>::load(qp + sub * VEC, q);
   RowVec<T>::load(qp + d + sub * VEC, kn);
   RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
-  const int bg = b + row0;  // global row: qkv / out are already offset to the half-batch, the KV pages are not
+  // global row: qkv / out are already offset to the half-batch, the KV pages are not
+  const int bg = MODE == 0 ? b + row0 : b / npos;
   const int32_t* pt = page_table + bg * pages_per_seq;
   auto page_of = [&](int t) { return identity_pages ? bg * pages_per_seq + t / PAGE : pt[t / PAGE]; };
-  if (wave == 0 && rin == 0) {  // append this step's k, v
+  if (MODE != 2 && wave == 0 && rin == 0) {  // append this step's k, v
     const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
     T* vdst = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (pos % PAGE)) * 64;
     *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
     *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
   }
+  if (MODE == 1) return;
   // this lane's slot: rows t = (it*4 + wave)*RPI + rin of the cached keys 0..pos-1
   float m_run = -1e30f, l_run = 0.f, acc[VEC];
 #pragma unroll
@@ -214,9 +222,21 @@ template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                              int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s) {
   // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
-  hipLaunchKernelGGL(self_attn_decode_kernel<T>, dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, identity_pages, row0, step, out, H);
+  hipLaunchKernelGGL((self_attn_decode_kernel<T, 0>), dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
+                     pages_per_seq, identity_pages, row0, step, out, H, 1);
 }
+// prompt prefill: rows = n_seq * npos, row-major [sequence][position]; positions 0..npos-1 of every sequence
+template <typename T>
+void launch_self_attn_prefill(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
+                              int identity_pages, T* out, int n_seq, int npos, int H, hipStream_t s) {
+  hipLaunchKernelGGL((self_attn_decode_kernel<T, 1>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
+                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos);
+  hipLaunchKernelGGL((self_attn_decode_kernel<T, 2>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
+                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos);
+}
+template void launch_self_attn_prefill<float>(const float*, float*, const int32_t*, int, int64_t, int, float*, int, int, int, hipStream_t);
+template void launch_self_attn_prefill<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, bf16_t*, int, int, int,
+                                               hipStream_t);
 
 // copy-on-write of partially filled KV pages after a beam re-index: pairs (src, dst) x all layers
 template <typename T>

@@ -22,6 +22,24 @@ void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T
 template void launch_embed<float>(const int32_t*, const int32_t*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_embed<bf16_t>(const int32_t*, const int32_t*, const bf16_t*, const bf16_t*, float*, int, int, hipStream_t);
 
+// prompt prefill: row b = position (b % npos) of sequence (b / npos); token from the uploaded prompt table
+template <typename T>
+__global__ __launch_bounds__(256) void embed_prefill_kernel(const int32_t* __restrict__ prompt, int max_prompt, int rows_per_prompt,
+                                                            int npos, const T* __restrict__ emb, const T* __restrict__ pos,
+                                                            float* __restrict__ x, int d) {
+  const int b = blockIdx.x, seq = b / npos, p = b % npos;
+  const int tok = prompt[(int64_t)(seq / rows_per_prompt) * max_prompt + p];
+  for (int i = threadIdx.x; i < d; i += 256) x[(int64_t)b * d + i] = to_f<T>(emb[(int64_t)tok * d + i]) + to_f<T>(pos[(int64_t)p * d + i]);
+}
+template <typename T>
+void launch_embed_prefill(const int32_t* prompt, int max_prompt, int rows_per_prompt, int n_seq, int npos, const T* emb, const T* pos,
+                          float* x, int d, hipStream_t s) {
+  hipLaunchKernelGGL(embed_prefill_kernel<T>, dim3(n_seq * npos), dim3(256), 0, s, prompt, max_prompt, rows_per_prompt, npos, emb,
+                     pos, x, d);
+}
+template void launch_embed_prefill<float>(const int32_t*, int, int, int, int, const float*, const float*, float*, int, hipStream_t);
+template void launch_embed_prefill<bf16_t>(const int32_t*, int, int, int, int, const bf16_t*, const bf16_t*, float*, int, hipStream_t);
+
 __global__ void advance_kernel(int32_t* step) { *step += 1; }
 void launch_advance(int32_t* step, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step); }
 
