@@ -134,7 +134,8 @@ template <typename T>
 void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s);
 template <typename T>
 void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B / kv_div][H][Tk][64]*/, T* out, int B, int H,
-                              int Tk, int kv_div, hipStream_t s);
+                              int Tk, int kv_div, hipStream_t s,
+                              float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/);
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
 // per-row history state uploaded by the host)
 struct BeamRowState { const int32_t *n_sampled, *last_tok, *pen_tok, *last_ts; const uint8_t* mask; };

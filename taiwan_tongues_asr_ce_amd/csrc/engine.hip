@@ -78,6 +78,7 @@ struct ttasr_ctx {
   float* x = nullptr; void *h = nullptr, *qkv = nullptr, *att = nullptr, *mid = nullptr, *enc_out = nullptr;
   void* xkv = nullptr; int64_t xkv_layer_elems = 0, xkv_which_elems = 0;
   void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
+  float* xsplit_ws = nullptr;  // split-frame cross-attention (small batches)
   float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
   float* rows_out = nullptr;
   int kv_div = 1;            // rows per clip sharing one cross-KV (beam width); 1 for greedy
@@ -90,6 +91,7 @@ struct ttasr_ctx {
   int max_new_alloc = 0, max_prompt_alloc = 0;
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
+  bool no_xsplit = false;   // TTASR_NO_XSPLIT: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // TTASR_NO_PREFILL: feed prompts token by token (A/B testing)
   hipEvent_t ev[8]{};
   float phase_ms[4]{0, 0, 0, 0};
@@ -281,6 +283,7 @@ int build_workspaces(ttasr_ctx* c) {
   c->xkv_which_elems = B * H * T * 64;
   c->xkv_layer_elems = 2 * c->xkv_which_elems;
   TRY(alloc_mat(c, &c->xkv, c->xkv_layer_elems * c->cfg.dec_layers));
+  TRY(dalloc(c, &c->xsplit_ws, (size_t)B * H * 8 * 66 * 4));
   c->pages_per_seq = (c->cfg.n_text_ctx + 15) / 16;
   const int64_t n_pages = B * c->pages_per_seq;
   c->pool_layer_elems = n_pages * 2 * H * 16 * 64;
@@ -446,7 +449,8 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
     // cross-KV of clip (row / kv_div); a half-batch offset is only used with kv_div == 1
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
     if (!(c->skip_mask & 8))
-      launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s);
+      launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
+                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66);
     { GemmArgs g = lin_args<T>(datt, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.wox_sh); }
     { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; ln_gemm(L.ln3g, L.ln3b, g, L.w1_sh); }
     { GemmArgs g = lin_args<T>(dmid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.w2_sh); }
@@ -641,6 +645,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
   c->no_prefill = getenv("TTASR_NO_PREFILL") != nullptr;
+  c->no_xsplit = getenv("TTASR_NO_XSPLIT") != nullptr;
   if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };

@@ -274,7 +274,7 @@ __device__ __forceinline__ void epi_store4(const GemmEpi& e, int64_t zoff, int m
 }
 
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-  constexpr int BM = 256, BN = 128, BK = 64, NSTAGE = 3;
+  constexpr int BM = 256, BN = 128, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;  // 32K + 16K
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
