@@ -55,3 +55,59 @@ def test_broadcast_and_gather_world2():
     assert allt.shape == (6, 6)
     assert allt[0].tolist() == [0, -1, -1, -1, -1, -1] and allt[2].tolist() == [200, 201, 202, -1, -1, -1]
     assert allt[3].tolist() == [300, 301, 302, 303, -1, -1] and allt[5].tolist() == [-1] * 6
+
+
+class _Seg:
+    def __init__(self, text):
+        self.text = text
+
+
+class _EchoModel:
+    """Model double: 'transcribes' a clip into its sample count, so every rank's share is recognisable."""
+
+    def transcribe(self, audio, **kw):
+        return iter([_Seg(f"長度{len(audio)}")]), None
+
+
+def _folder_worker(rank, world, port, folder, out_json, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from taiwan_tongues_asr_ce_amd import batch_cli
+    from taiwan_tongues_asr_ce_amd.dist import init_process_group
+    r, w, _ = init_process_group("gloo")
+    seen = []
+    final = batch_cli.process_audio_folder(folder, model=_EchoModel(), output_json=out_json, rank=r, world=w,
+                                           load_audio=lambda p: (seen.append(os.path.basename(p)), np.zeros(int(os.path.basename(p)[1:3]) * 10, np.float32))[1],
+                                           log=lambda *_: None)
+    q.put((r, seen, [d["audio_file"] for d in final["detailed_results"]], final["summary"]["total_files"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_folder_tool_shards_files_across_ranks(tmp_path):
+    """asr_core-equivalent folder tool under 2 ranks: files (never windows) are dealt round-robin, every rank ends
+    with the complete, identically ordered result list, rank 0 alone writes the summary JSON."""
+    import json
+    folder = tmp_path / "audio"
+    folder.mkdir()
+    names = [f"c{n:02d}.wav" for n in (11, 12, 13, 14, 15)]
+    for n in names:
+        (folder / n).write_bytes(b"")
+    out_json = str(tmp_path / "summary.json")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_folder_worker, args=(r, 2, port, str(folder), out_json, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == names[0::2] and res[1][1] == names[1::2]          # who transcribed what
+    assert res[0][2] == res[1][2] == names and res[0][3] == 5             # merged view, original order
+    on_disk = json.load(open(out_json, encoding="utf-8"))
+    assert [d["asr_result"] for d in on_disk["detailed_results"]] == [f"長度{n}0" for n in (11, 12, 13, 14, 15)]
+    for n in names:
+        assert (folder / (n[:-4] + "_asr.txt")).exists()
