@@ -195,6 +195,16 @@ def main():
             eng.bench_kernel(n, B, iters=10)
         gs = [eng.bench_kernel(n, B, iters=30) for n in names]
         enc_tf = sum(x["flops"] for x in gs) / (sum(x["ms"] for x in gs) * 1e-3) / 1e12
+        # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent)
+        pmc_busy = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_k_pmc.json")) as f:
+                kk_ = json.load(f)["kernels"]
+            fr = [kk_["enc qkv GEMM (EPI 0)"]["mfma_busy_frac"], kk_["enc out-proj / fc2 GEMM + f32 residual (EPI 18)"]["mfma_busy_frac"],
+                  kk_["enc fc1 GEMM + GELU (EPI 1)"]["mfma_busy_frac"], kk_["enc out-proj / fc2 GEMM + f32 residual (EPI 18)"]["mfma_busy_frac"]]
+            pmc_busy = round(sum(x["flops"] for x in gs) / sum(x["flops"] / f_ for x, f_ in zip(gs, fr)), 4)
+        except Exception:
+            pass
         ph = {kk: round(float(np.mean([p[kk] for p in phases])), 2) for kk in phases[0]}
         out = {
             "metric": "audio-sec/s (RTF) whisper-large-v3 greedy, 30 s clips, batch 32; 1/2/4/8 GPU",
@@ -210,7 +220,7 @@ def main():
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
-                     "frac": round(enc_tf / 2500.0, 4)},
+                     "frac": round(enc_tf / 2500.0, 4), "pmc_mfma_busy_frac": pmc_busy},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, args.new_tokens)
