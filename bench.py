@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="opt-in serving configuration: this many independent engine contexts per GPU, each running the "
+                         "whole step on its own batch of --batch clips from its own host thread (clips in flight per GPU "
+                         "= contexts x batch; the latency-bound decode chains of one context fill the gaps of the other)")
     args = ap.parse_args()
 
     import torch
@@ -108,16 +112,20 @@ def main():
     rank, world, local = init_process_group()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = local % max(torch.cuda.device_count(), 1)   # ranks > devices only in the shared-GPU plumbing smoke test
     torch.cuda.set_device(local)
     dims = PRESETS[args.model]
     B = args.batch
-    eng = Engine(dims, COMPUTE_BF16 if args.compute == "bf16" else COMPUTE_F32, B, device=local)
+    C_ = max(1, args.contexts)
+    engines = [Engine(dims, COMPUTE_BF16 if args.compute == "bf16" else COMPUTE_F32, B, device=local) for _ in range(C_)]
+    eng = engines[0]
     t_load = time.perf_counter()
-    if world > 1 and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
-        # north_star: rank 0 owns the checkpoint, the others receive it over RCCL (xGMI broadcast, 256 MB buckets)
-        broadcast_weights(eng, dims, src_iter=synth.iter_weights(dims) if rank == 0 else None, device=local)
-    else:
-        eng.load_weights(synth.iter_weights(dims))
+    for e_ in engines:
+        if world > 1 and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
+            # north_star: rank 0 owns the checkpoint, the others receive it over RCCL (xGMI broadcast, 256 MB buckets)
+            broadcast_weights(e_, dims, src_iter=synth.iter_weights(dims) if rank == 0 else None, device=local)
+        else:
+            e_.load_weights(synth.iter_weights(dims))
     t_load = time.perf_counter() - t_load
 
     # synthetic clips: rank r owns clips [r*B, (r+1)*B) of the global batch (weak scaling)
@@ -125,15 +133,36 @@ def main():
     for b in range(B):
         pcm[b] = torch.from_numpy(synth.noise_clip(rank * B + b)).to(pcm.device)
     ns = [480000] * B
+    torch.cuda.synchronize()    # the engine reads pcm on its own (non-blocking) stream
     st = eng.special
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
     opts = eng.gen_opts(args.new_tokens, timestamps=False, suppress_eot=True, no_speech=True, check_interval=1 << 20)
 
+    def one_pass(e_):
+        e_.log_mel_device(pcm.data_ptr(), 480000, ns)
+        e_.encode(B)
+        return e_.generate([prompt] * B, opts).tokens
+
     def step():
-        eng.log_mel_device(pcm.data_ptr(), 480000, ns)
-        eng.encode(B)
-        res = eng.generate([prompt] * B, opts)
-        return gather_tokens(res.tokens, args.new_tokens, device=local)
+        if C_ == 1:
+            return gather_tokens(one_pass(eng), args.new_tokens, device=local)
+        # --contexts N: one step = every context passes its own batch, concurrently (ctypes releases the GIL)
+        import threading
+        out, errs = [None] * C_, []
+
+        def run(i):
+            try:
+                out[i] = one_pass(engines[i])
+            except Exception as ex:
+                errs.append(ex)
+        th = [threading.Thread(target=run, args=(i,)) for i in range(C_)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
+        return gather_tokens([t for o in out for t in o], args.new_tokens, device=local)
 
     for _ in range(args.warmup):
         step()
@@ -152,10 +181,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert toks.shape == (world * B, args.new_tokens)
+    assert toks.shape == (world * B * C_, args.new_tokens)
 
     # PCIe-inclusive variant (never `value`): the same step with the PCM handed over as a pinned host buffer
     host_ms = None
@@ -208,14 +237,15 @@ def main():
         ph = {kk: round(float(np.mean([p[kk] for p in phases])), 2) for kk in phases[0]}
         out = {
             "metric": "audio-sec/s (RTF) whisper-large-v3 greedy, 30 s clips, batch 32; 1/2/4/8 GPU",
-            "value": round(world * B * 30.0 * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world,
+            "value": round(world * C_ * B * 30.0 * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
-            "config": {"workload": f"whisper-{args.model} geometry (random-init seeded weights), {B} x 30 s 16 kHz synthetic "
+            "config": {"workload": f"whisper-{args.model} geometry (random-init seeded weights), " + (f"{C_} concurrent contexts x " if C_ > 1 else "") + f"{B} x 30 s 16 kHz synthetic "
                                    f"clips per GPU resident in HBM, log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
-                       "clips_per_gpu": B, "new_tokens": args.new_tokens, "parallelism": f"dp{world}",
+                       "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens,
+                       "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else ""),
                        "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
@@ -225,7 +255,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, args.new_tokens)
         print(json.dumps(out), flush=True)
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
