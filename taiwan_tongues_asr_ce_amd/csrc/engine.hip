@@ -867,6 +867,8 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   const int A = R / rows_per_clip;
   for (int a = 0; a < A; ++a) {
     if (prompt_len[a] < 1 || prompt_len[a] > max_prompt) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", a, prompt_len[a]);
+    if (prompt_len[a] >= c->cfg.n_text_ctx)
+      return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d leaves no room in the %d-token context", a, prompt_len[a], c->cfg.n_text_ctx);
     min_plen = std::min(min_plen, prompt_len[a]); max_plen = std::max(max_plen, prompt_len[a]);
     for (int j = 0; j < prompt_len[a]; ++j)
       if (prompt[a * max_prompt + j] < 0 || prompt[a * max_prompt + j] >= c->V)
@@ -893,7 +895,9 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   c->kv_div = rows_per_clip;
   struct Restore { ttasr_ctx* c; ~Restore() { c->kv_div = 1; } } restore{c};
   const int interval = std::max(1, o->check_interval);
-  const int last_step = std::min(c->cfg.n_text_ctx, max_plen - 1 + o->max_new_tokens);  // exclusive
+  // exclusive; prompt + sampled tokens never exceed n_text_ctx (the reference's max_length = 448: the token sampled
+  // from position n_text_ctx - 2 is the last one, position n_text_ctx - 1 is never fed)
+  const int last_step = std::min(c->cfg.n_text_ctx - 1, max_plen - 1 + o->max_new_tokens);
   hipEventRecord(c->ev[5], s);
   const int pre = prefill_positions(c, min_plen, o);
   if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
@@ -1022,7 +1026,7 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pre];
   }
   bool stop = false;
-  for (int pos = pre; pos < c->cfg.n_text_ctx && !stop; ++pos) {
+  for (int pos = pre; pos < c->cfg.n_text_ctx - 1 && !stop; ++pos) {
     // 1. the page this step writes must exist and be private to the row (copy-on-write after a re-index)
     const int j = pos / 16;
     pairs.clear();
