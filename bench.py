@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--validate", action="store_true",
+                    help="multi-GPU validation mode: every rank decodes the same probe clip and the first-step logits are "
+                         "gathered and compared (proves the RCCL weight broadcast)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="opt-in serving configuration: this many independent engine contexts per GPU, each running the "
                          "whole step on its own batch of --batch clips from its own host thread (clips in flight per GPU "
@@ -186,6 +189,17 @@ def main():
         dt = float(t.item())
     assert toks.shape == (world * B * C_, args.new_tokens)
 
+    logits_spread = None
+    if args.validate:
+        from taiwan_tongues_asr_ce_amd.dist import gather_logits
+        eng.log_mel([synth.noise_clip(0)], want_output=False)        # the SAME clip on every rank
+        eng.encode(1)
+        eng.decode_reset(1)
+        all_lg = gather_logits(eng.decode_step([st.sot]), device=local)
+        logits_spread = float(np.abs(all_lg - all_lg[0:1]).max())
+        if logits_spread > (2e-2 if args.compute == "bf16" else 1e-4):   # bf16: atomics reorder the last bits only
+            raise SystemExit(f"validation failed: first-step logits differ across ranks by {logits_spread}")
+
     # PCIe-inclusive variant (never `value`): the same step with the PCM handed over as a pinned host buffer
     host_ms = None
     if rank == 0:
@@ -246,7 +260,7 @@ def main():
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
                        "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens,
                        "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else ""),
-                       "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
+                       "rank_logits_spread": logits_spread, "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,

@@ -96,3 +96,17 @@ def gather_tokens(tokens: Sequence[Sequence[int]], max_len: int, device=None, pa
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return torch.cat(out, dim=0).cpu().numpy()
+
+
+def gather_logits(logits: np.ndarray, device=None) -> np.ndarray:
+    """Validation mode: every rank's float32 [rows][vocab] first-step logits as one
+    [world][rows][vocab] array on every rank.  Used to prove the broadcast weights are bit-identical everywhere: all
+    ranks decode the same probe clip and must produce the same logits."""
+    local = np.ascontiguousarray(logits, dtype=np.float32)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local[None]
+    dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
+    mine = torch.from_numpy(local).to(dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.stack(out, dim=0).cpu().numpy()

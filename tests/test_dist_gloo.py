@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import PRESETS
-    from taiwan_tongues_asr_ce_amd.dist import broadcast_tensors, gather_tokens, init_process_group, shard_range
+    from taiwan_tongues_asr_ce_amd.dist import broadcast_tensors, gather_logits, gather_tokens, init_process_group, shard_range
     r, w, _ = init_process_group("gloo")
     dims = PRESETS["micro"]
     src = synth.iter_weights(dims) if r == 0 else None
@@ -33,6 +33,8 @@ def _worker(rank, world, port, q):
     n_max = max(shard_range(5, rr, w)[1] - shard_range(5, rr, w)[0] for rr in range(w))
     toks += [[]] * (n_max - len(toks))
     allt = gather_tokens(toks, 6)
+    lg = gather_logits(np.full((2, 7), float(r), np.float32))
+    ok = ok and lg.shape == (w, 2, 7) and all(float(lg[rr].min()) == float(lg[rr].max()) == rr for rr in range(w))
     q.put((r, ok, allt.tolist()))
     dist.barrier()
     dist.destroy_process_group()
