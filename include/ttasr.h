@@ -147,6 +147,21 @@ int ttasr_decode_step(ttasr_ctx* ctx, const int32_t* tokens_host, int32_t B, flo
 int ttasr_apply_rules(ttasr_ctx* ctx, const float* rows_host, const int32_t* hist_host, int32_t hist_stride,
                       int32_t n, const ttasr_gen_opts* opts, float* out_rows_host, int32_t* out_choice_host);
 
+/* ---- word timestamps (faster-whisper find_alignment -> ctranslate2 Whisper.align; WhisperModel.transcribe(word_timestamps=True),
+ * requested at faster_whisper_asr.py:289-294) -------------------------------------------------------------------------- */
+/* Teacher-forces tokens_host[0..n_tokens) (sot sequence + text tokens + eot) against the resident encoder state of
+ * clip `clip` in one batched pass and returns
+ *   out_weights_host  float32 [n_pairs][n_tokens][n_ctx]  softmax cross-attention rows of the (layer, head) pairs
+ *                     pairs_host[2*i], pairs_host[2*i+1]   (n_ctx = the current audio window, 1500 by default)
+ *   out_logprob_host  optional float32 [n_tokens - 1]       log p(tokens[i+1] | tokens[0..i]) from the raw logits.
+ * Invalidates any step-level decode state (it reuses row 0's self-attention pages). */
+int ttasr_align(ttasr_ctx* ctx, int32_t clip, const int32_t* tokens_host, int32_t n_tokens, const int32_t* pairs_host,
+                int32_t n_pairs, float* out_weights_host, float* out_logprob_host);
+/* Host-side dynamic time warping over a row-major cost matrix [n_rows][n_cols] (tokens x frames): the monotone path
+ * of minimum total cost from (0,0) to (n_rows-1, n_cols-1); out_row / out_col need n_rows + n_cols entries.  Pure CPU
+ * (no context): CTranslate2 does this step in C++ too. */
+int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_row, int32_t* out_col, int32_t* out_len);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* hipEvent times (ms) of the last log_mel / encode (stem+layers, cross-KV) / generate calls:
  * out[0]=mel out[1]=encoder out[2]=cross_kv out[3]=decode. */

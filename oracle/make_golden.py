@@ -195,9 +195,49 @@ def golden_rules():
     print("rules.npz", len(rows))
 
 
+def golden_align():
+    """Token-level timestamps (the `.words` path): HF cross-attentions of chosen alignment heads for a fixed token
+    sequence and what `WhisperGenerationMixin._extract_token_timestamps` (median filter 7, DTW) makes of them."""
+    from transformers.utils import ModelOutput
+    out = {}
+    for name, n_text in (("micro", 14), ("tiny", 40)):
+        dims = PRESETS[name]
+        model, st = hf_model(dims)
+        fe = WhisperFeatureExtractor(feature_size=dims.n_mels, chunk_length=dims.n_frames // 100)
+        n = dims.n_frames * 160
+        pcm = synth.noise_clip(7, n) if name == "micro" else synth.tonal_clip(7)
+        mel = fe(pcm, sampling_rate=16000, return_tensors="np")["input_features"]
+        enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state
+        rng = np.random.default_rng(11)
+        hi = min(dims.vocab, st.eot) if st.eot > 300 else dims.vocab
+        text = rng.integers(10, max(11, min(hi, 20000)), size=n_text).tolist()
+        prefix = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+        tokens = prefix + text + [st.eot]
+        heads = [[dims.dec_layers - 1, 0], [dims.dec_layers - 1, dims.n_heads - 1], [dims.dec_layers // 2, 1 % dims.n_heads]]
+        o = model.model.decoder(input_ids=torch.tensor([tokens]), encoder_hidden_states=enc, output_attentions=True)
+        cross = o.cross_attentions                                   # tuple(L) of [1, H, n_tok, T]
+        w = torch.stack([cross[l][0, h] for l, h in heads])
+        lp = torch.log_softmax(model.proj_out(o.last_hidden_state)[0, :-1], dim=-1)
+        tok_lp = lp[torch.arange(len(tokens) - 1), torch.tensor(tokens[1:])]
+        go = ModelOutput(cross_attentions=[tuple(cross)], sequences=torch.tensor([tokens]))
+        for tag, nf in (("full", dims.n_frames), ("short", (dims.n_frames * 2 // 3) // 2 * 2)):
+            ts = model._extract_token_timestamps(go, heads, num_frames=nf, num_input_ids=len(prefix))
+            out[f"{name}_ts_{tag}"] = ts[0].numpy()
+            out[f"{name}_nf_{tag}"] = np.array(nf)
+        out[f"{name}_pcm_seed"] = np.array(7)
+        out[f"{name}_tokens"] = np.array(tokens)
+        out[f"{name}_n_prefix"] = np.array(len(prefix))
+        out[f"{name}_heads"] = np.array(heads)
+        out[f"{name}_weights"] = w.numpy().astype(np.float16 if name == "tiny" else np.float32)
+        out[f"{name}_token_logprob"] = tok_lp.numpy()
+    np.savez_compressed(os.path.join(OUT, "align.npz"), **out)
+    print("align.npz", {k: v.shape for k, v in out.items() if "ts_" in k or "weights" in k})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_mel()
     golden_rules()
     golden_micro()
     golden_tiny()
+    golden_align()

@@ -227,10 +227,11 @@ class SelfCache:
         return 0 if self.k[0] is None else self.k[0].shape[2]
 
 
-def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, torch.Tensor], dims: Dims
-                    ) -> torch.Tensor:
+def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, torch.Tensor], dims: Dims,
+                    cross_probs: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """tokens [B,n] appended at positions cache.length.. ; returns logits [B,n,V] ([HF-M]:737-790, 1080).
-    n > 1 applies the causal mask among the new tokens."""
+    n > 1 applies the causal mask among the new tokens.  If `cross_probs` is a list, the cross-attention
+    probabilities [B,H,n,T] of every layer are appended to it (HF `output_attentions`, [HF-M]:347-356)."""
     B, n = tokens.shape
     H = dims.n_heads
     hd = dims.d_model // H
@@ -253,6 +254,8 @@ def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, to
         x = x + _lin(_attend(q, k, v, mask), W, p + ".self_attn.out_proj")
         h = _ln(x, W[p + ".encoder_attn_layer_norm.weight"], W[p + ".encoder_attn_layer_norm.bias"])
         q = _split_heads(_lin(h, W, p + ".encoder_attn.q_proj") * (hd ** -0.5), H)
+        if cross_probs is not None:
+            cross_probs.append(torch.softmax(q @ xkv[i][0].transpose(-1, -2), dim=-1))
         x = x + _lin(_attend(q, xkv[i][0], xkv[i][1]), W, p + ".encoder_attn.out_proj")
         h = _ln(x, W[p + ".final_layer_norm.weight"], W[p + ".final_layer_norm.bias"])
         x = x + _lin(_gelu(_lin(h, W, p + ".fc1")), W, p + ".fc2")
@@ -530,3 +533,81 @@ def sample_decode(enc: torch.Tensor, prompt: Sequence[int], W: Dict[str, torch.T
         best = max(rows, key=lambda r: (sum_lp[r] / max(len(sampled[r]), 1), -r))
         toks.append(sampled[best]); lps.append(sum_lp[best])
     return GreedyResult(toks, lps, [0.0] * A)
+
+
+# --------------------------------------------------------------------------------------------------
+# a2 (.words): token-level timestamps from cross-attention + dynamic time warping.  faster-whisper's
+# `find_alignment` calls CTranslate2 `Whisper.align` (un-vendored); HF restates the same published algorithm in
+# [HF-G] generation_whisper.py `_extract_token_timestamps` / `_median_filter` / `_dynamic_time_warping`, which is what
+# is followed (and pinned) here: select the alignment heads, crop to num_frames // 2, drop the prompt rows, normalise
+# each head over the TOKEN axis, median-filter along time (width 7, reflect), average the heads, DTW on the negated
+# matrix, a token starts where the path first enters its row.
+# --------------------------------------------------------------------------------------------------
+def alignment_weights(enc: torch.Tensor, tokens: Sequence[int], W: Dict[str, torch.Tensor], dims: Dims,
+                      heads: Sequence[Tuple[int, int]], return_logprobs: bool = False):
+    """Teacher-forced pass over `tokens` for ONE clip: cross-attention probabilities of the (layer, head) pairs,
+    [n_pairs, n_tok, T]; optionally log p(tokens[i+1] | tokens[:i+1]) from the raw logits, [n_tok - 1]."""
+    xkv = cross_kv(enc, W, dims)
+    cache = SelfCache.empty(dims.dec_layers)
+    probs: List[torch.Tensor] = []
+    logits = decoder_forward(torch.tensor([list(tokens)]), cache, xkv, W, dims, cross_probs=probs)
+    w = torch.stack([probs[l][0, h] for l, h in heads])
+    if not return_logprobs:
+        return w
+    lp = torch.log_softmax(logits[0, :-1], dim=-1)
+    return w, lp[torch.arange(len(tokens) - 1), torch.tensor(list(tokens[1:]))]
+
+
+def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
+    pad = width // 2
+    if x.shape[-1] <= pad:
+        return x
+    xp = F.pad(x, (pad, pad, 0, 0), mode="reflect")
+    return xp.unfold(-1, width, 1).sort()[0][..., pad]
+
+
+def dtw_path(cost: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Monotone alignment path of minimum total cost through an [n_tok, n_frames] matrix; on ties the horizontal
+    move wins, then the vertical one (the branch order of the published implementation)."""
+    n, m = cost.shape
+    acc = np.full((n + 1, m + 1), np.inf, dtype=np.float32)
+    trace = -np.ones((n + 1, m + 1), dtype=np.int8)
+    acc[0, 0] = 0
+    for j in range(1, m + 1):
+        for i in range(1, n + 1):
+            c0, c1, c2 = acc[i - 1, j - 1], acc[i - 1, j], acc[i, j - 1]
+            if c0 < c1 and c0 < c2:
+                c, t = c0, 0
+            elif c1 < c0 and c1 < c2:
+                c, t = c1, 1
+            else:
+                c, t = c2, 2
+            acc[i, j] = np.float32(cost[i - 1, j - 1]) + c
+            trace[i, j] = t
+    trace[0, :] = 2
+    trace[:, 0] = 1
+    i, j, ti, tj = n, m, [], []
+    while i > 0 or j > 0:
+        ti.append(i - 1)
+        tj.append(j - 1)
+        t = trace[i, j]
+        if t == 0:
+            i, j = i - 1, j - 1
+        elif t == 1:
+            i -= 1
+        else:
+            j -= 1
+    return np.array(ti)[::-1], np.array(tj)[::-1]
+
+
+def token_timestamps(weights: torch.Tensor, n_prefix: int, num_frames: Optional[int] = None, medfilt: int = 7,
+                     time_precision: float = 0.02) -> np.ndarray:
+    """weights [n_pairs, n_tok, T] -> start time of every token after the first n_prefix (seconds)."""
+    w = weights if num_frames is None else weights[..., : num_frames // 2]
+    w = w[:, n_prefix:, :]
+    std = torch.std(w, dim=-2, keepdim=True, unbiased=False)
+    mean = torch.mean(w, dim=-2, keepdim=True)
+    w = median_filter((w - mean) / std, medfilt).mean(dim=0)
+    ti, tj = dtw_path(-w.double().numpy())
+    jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+    return tj[jumps] * time_precision

@@ -78,7 +78,8 @@ class MI355XWhisperASR(ASRInterface):
         wav = os.environ.get("TTASR_WARMUP_WAV")
         try:
             if wav and os.path.exists(wav):
-                segs, _ = self.asr_pipeline.transcribe(wav, language="zh", initial_prompt="繁體中文", beam_size=1)
+                # faster_whisper_asr.py:289-294: the warm-up asks for word timestamps, which also warms the alignment pass
+                segs, _ = self.asr_pipeline.transcribe(wav, word_timestamps=True, language="zh", initial_prompt="繁體中文")
             else:
                 segs, _ = self.asr_pipeline.transcribe(np.zeros(16000, np.float32), language="zh", beam_size=1)
             list(segs)

@@ -477,13 +477,20 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
 // these positions is followed by another forced prompt token), so the pass borrows the encoder's activation
 // workspaces, which are idle once the cross-KV is built.  Sequence s attends to the cross-KV of clip s / seq_per_clip.
 // GEMMs go through the encoder dispatch (M = n_seq * npos rows; 256x256 MFMA tiles once M >= 256).
+// Alignment variant (ttasr_align): one sequence of clip `al->clip`; the cross-attention rows of the selected
+// (layer, head) pairs are written to al->probs, and the residual stream is left in c->x for the token log-probs.
+struct AlignOut {
+  int clip;
+  const int* sel;   // device [dec_layers][H]: index into probs or -1
+  float* probs;     // device [n_sel][npos][T]
+};
 template <typename T>
-void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip) {
+void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_prompt, const AlignOut* al = nullptr) {
   const int d = c->d, ffn = c->ffn, n = n_seq * npos;
   hipStream_t s = c->cur = c->stream;
   float* x = c->x;
   void *h = c->h, *qkv = c->qkv, *att = c->att, *mid = c->mid;
-  launch_embed_prefill<T>(c->prompt_dev, c->rp.max_prompt, 1, n_seq, npos, (const T*)c->emb, (const T*)c->dpos, x, d, s);
+  launch_embed_prefill<T>(c->prompt_dev, max_prompt, 1, n_seq, npos, (const T*)c->emb, (const T*)c->dpos, x, d, s);
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
     launch_layernorm<T>(x, L.ln1g, L.ln1b, (T*)h, n, d, s);
@@ -494,7 +501,13 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip) {
     launch_layernorm<T>(x, L.ln2g, L.ln2b, (T*)h, n, d, s);
     { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = qkv; gemm<T>(c, g); }  // q reuses the qkv buffer
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
-    launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s);
+    if (al) {
+      const T* Kc = Kx + (int64_t)al->clip * c->H * c->T * 64;
+      launch_cross_attn_probs<T>((const T*)qkv, Kc, Kc + c->xkv_which_elems, (T*)att, n, c->H, c->T, al->sel + (size_t)l * c->H,
+                                 al->probs, s);
+    } else {
+      launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s);
+    }
     { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
     launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);
     { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; gemm<T>(c, g); }
@@ -901,7 +914,7 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   hipEventRecord(c->ev[5], s);
   const int pre = prefill_positions(c, min_plen, o);
   if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
-    if (c->bf16) run_prefill<bf16_t>(c, R, pre, rows_per_clip); else run_prefill<float>(c, R, pre, rows_per_clip);
+    if (c->bf16) run_prefill<bf16_t>(c, R, pre, rows_per_clip, max_prompt); else run_prefill<float>(c, R, pre, rows_per_clip, max_prompt);
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev + pre, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
@@ -1019,7 +1032,7 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     HIPCHK(c, hipMemcpyAsync(c->page_table, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * plen * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));  // ptab is a stack temporary
-    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1); else run_prefill<float>(c, A, pre, 1);
+    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1, plen); else run_prefill<float>(c, A, pre, 1, plen);
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
     rebuild_free(n_pg - 1);
@@ -1193,6 +1206,88 @@ int ttasr_sync(ttasr_ctx* c) {
   if (!c) return TTASR_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return TTASR_OK;
+}
+
+int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok, const int32_t* pairs, int32_t n_pairs,
+                float* out_weights, float* out_logprob) {
+  TRY(check_ready(c, 1));
+  if (!tokens || !pairs || !out_weights) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (clip < 0 || clip >= c->B_enc) return fail(c, TTASR_E_INVALID, "clip %d but the encoder state holds %d", clip, c->B_enc);
+  if (n_tok < 2 || n_tok > c->cfg.n_text_ctx || n_tok > c->cfg.n_audio_ctx)
+    return fail(c, TTASR_E_INVALID, "n_tokens %d outside [2, min(n_text_ctx, n_audio_ctx)]", n_tok);
+  if (n_pairs < 1 || n_pairs > c->cfg.dec_layers * c->H) return fail(c, TTASR_E_INVALID, "n_pairs %d", n_pairs);
+  for (int i = 0; i < n_tok; ++i)
+    if (tokens[i] < 0 || tokens[i] >= c->V) return fail(c, TTASR_E_INVALID, "token outside vocabulary");
+  std::vector<int32_t> sel((size_t)c->cfg.dec_layers * c->H, -1);
+  for (int i = 0; i < n_pairs; ++i) {
+    const int l = pairs[2 * i], h = pairs[2 * i + 1];
+    if (l < 0 || l >= c->cfg.dec_layers || h < 0 || h >= c->H) return fail(c, TTASR_E_INVALID, "alignment head (%d, %d)", l, h);
+    if (sel[(size_t)l * c->H + h] >= 0) return fail(c, TTASR_E_INVALID, "alignment head (%d, %d) listed twice", l, h);
+    sel[(size_t)l * c->H + h] = i;
+  }
+  hipStream_t s = c->stream;
+  const size_t n_w = (size_t)n_pairs * n_tok * c->T;
+  float* probs = nullptr; int32_t* sel_dev = nullptr; float* lp_dev = nullptr;
+  struct Free { void** p; ~Free() { if (*p) hipFree(*p); } } f1{(void**)&probs}, f2{(void**)&sel_dev}, f3{(void**)&lp_dev};
+  if (hipMalloc(&probs, n_w * 4) != hipSuccess || hipMalloc(&sel_dev, sel.size() * 4) != hipSuccess ||
+      hipMalloc(&lp_dev, (size_t)n_tok * 4) != hipSuccess)
+    return fail(c, TTASR_E_NOMEM, "alignment buffers (%zu bytes)", n_w * 4);
+  HIPCHK(c, hipMemcpyAsync(sel_dev, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->prompt_dev, tokens, (size_t)n_tok * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipStreamSynchronize(s));  // sel is a stack temporary
+  c->B_dec = 0;  // the pass reuses sequence 0's self-attention pages: any step-level decode state is gone
+  AlignOut al{clip, sel_dev, probs};
+  if (c->bf16) run_prefill<bf16_t>(c, 1, n_tok, 1, n_tok, &al); else run_prefill<float>(c, 1, n_tok, 1, n_tok, &al);
+  if (out_logprob) {
+    // raw log p(tokens[i + 1] | tokens[0..i]): final LayerNorm + vocabulary projection, max_batch rows at a time
+    for (int r0 = 0; r0 < n_tok - 1; r0 += c->maxB) {
+      const int n = std::min(c->maxB, n_tok - 1 - r0);
+      c->cur = s;
+      if (c->bf16) {
+        launch_layernorm<bf16_t>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (bf16_t*)c->dh, n, c->d, s);
+        GemmArgs g = lin_args<bf16_t>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
+        dec_gemm<bf16_t>(c, g, c->emb_sh);
+      } else {
+        launch_layernorm<float>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (float*)c->dh, n, c->d, s);
+        GemmArgs g = lin_args<float>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
+        dec_gemm<float>(c, g, nullptr);
+      }
+      launch_token_logprob(c->logits, c->ldv, c->V, c->prompt_dev + r0 + 1, lp_dev + r0, n, s);
+    }
+    HIPCHK(c, hipMemcpyAsync(out_logprob, lp_dev, (size_t)(n_tok - 1) * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(c, hipMemcpyAsync(out_weights, probs, n_w * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  return TTASR_OK;
+}
+
+int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_row, int32_t* out_col, int32_t* out_len) {
+  if (!cost || !out_row || !out_col || !out_len || n_rows < 1 || n_cols < 1) return TTASR_E_INVALID;
+  const size_t W_ = (size_t)n_cols + 1;
+  std::vector<float> acc(((size_t)n_rows + 1) * W_, INFINITY);
+  std::vector<int8_t> trace(((size_t)n_rows + 1) * W_, -1);
+  acc[0] = 0.f;
+  for (int j = 1; j <= n_cols; ++j)
+    for (int i = 1; i <= n_rows; ++i) {
+      const float c0 = acc[(size_t)(i - 1) * W_ + j - 1], c1 = acc[(size_t)(i - 1) * W_ + j], c2 = acc[(size_t)i * W_ + j - 1];
+      float best; int8_t t;
+      if (c0 < c1 && c0 < c2) { best = c0; t = 0; } else if (c1 < c0 && c1 < c2) { best = c1; t = 1; } else { best = c2; t = 2; }
+      acc[(size_t)i * W_ + j] = cost[(size_t)(i - 1) * n_cols + j - 1] + best;
+      trace[(size_t)i * W_ + j] = t;
+    }
+  for (int j = 0; j <= n_cols; ++j) trace[j] = 2;
+  for (int i = 0; i <= n_rows; ++i) trace[(size_t)i * W_] = 1;
+  int i = n_rows, j = n_cols, n = 0;
+  while (i > 0 || j > 0) {  // at most n_rows + n_cols entries, written back to front then reversed
+    out_row[n] = i - 1; out_col[n] = j - 1; ++n;
+    const int8_t t = trace[(size_t)i * W_ + j];
+    if (t == 0) { --i; --j; } else if (t == 1) --i; else --j;
+  }
+  std::reverse(out_row, out_row + n);
+  std::reverse(out_col, out_col + n);
+  *out_len = n;
   return TTASR_OK;
 }
 

@@ -269,10 +269,13 @@ template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int3
 //   phase B  stream V: acc[j] += p[t] * v[t][j]; reduce over the row-slots of the wave, then over waves
 // Algorithmic bytes per launch: B*H*2*Tk*64*sizeof(T) (+ q, out): 245.8 MB per clip-step-layer... see DESIGN.md.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// PROBS = true is the alignment (word-timestamp) pass: heads listed in `sel` (sel[h] >= 0) also write their softmax
+// row to probs[sel[h]][b][0..Tk).  The PROBS = false instantiation is the decode-step kernel, unchanged.
+template <typename T, bool PROBS>
 __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
                                                                 const T* __restrict__ V, T* __restrict__ out, int H, int Tk,
-                                                                int kv_div) {
+                                                                int kv_div, const int* __restrict__ sel,
+                                                                float* __restrict__ probs) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = 8;
   extern __shared__ float sc[];  // [Tk] scores, then [4][64] partial outputs, [8] reductions
@@ -326,6 +329,14 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
   if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
   const float denom = (red[4] + red[5]) + (red[6] + red[7]);
+  if constexpr (PROBS) {
+    const int si = sel[h];
+    if (si >= 0) {
+      float* dst = probs + ((int64_t)si * gridDim.y + b) * Tk;
+      const float inv = 1.f / denom;
+      for (int t = tid; t < Tk; t += 256) dst[t] = sc[t] * inv;
+    }
+  }
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
@@ -506,8 +517,20 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
     return;
   }
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL(cross_attn_decode_kernel<T>, dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div);
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, false>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div,
+                     (const int*)nullptr, (float*)nullptr);
 }
+// alignment pass: rows = token positions of one sequence; heads with sel[h] >= 0 dump their attention rows
+template <typename T>
+void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel, float* probs,
+                             hipStream_t s) {
+  size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs);
+}
+template void launch_cross_attn_probs<float>(const float*, const float*, const float*, float*, int, int, int, const int*, float*,
+                                             hipStream_t);
+template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, const int*, float*,
+                                              hipStream_t);
 template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
                                                float*);

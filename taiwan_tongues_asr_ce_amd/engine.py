@@ -204,6 +204,19 @@ class Engine:
                                                    lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_sample")
         return GenResult([toks[a, :lens[a]].tolist() for a in range(A)], lp, ns)
 
+    def align(self, clip: int, tokens: Sequence[int], heads: Sequence[Tuple[int, int]], want_logprob: bool = True):
+        """Cross-attention rows of the (layer, head) pairs for a teacher-forced token sequence of one resident clip:
+        (weights float32 [n_heads][n_tokens][audio_ctx], logprob float32 [n_tokens - 1] or None)."""
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        pr = np.ascontiguousarray(heads, dtype=np.int32).reshape(-1, 2)
+        w = np.empty((len(pr), len(tok), self.audio_ctx), dtype=np.float32)
+        lp = np.empty(max(len(tok) - 1, 1), dtype=np.float32) if want_logprob else None
+        self._check(self.lib.ttasr_align(self.h, clip, tok.ctypes.data_as(C.POINTER(C.c_int32)), len(tok),
+                                         pr.ctypes.data_as(C.POINTER(C.c_int32)), len(pr),
+                                         w.ctypes.data_as(C.POINTER(C.c_float)),
+                                         lp.ctypes.data_as(C.POINTER(C.c_float)) if want_logprob else None), "align")
+        return w, (lp[: len(tok) - 1] if want_logprob else None)
+
     def decode_reset(self, B: int):
         self._check(self.lib.ttasr_decode_reset(self.h, B), "decode_reset")
 

@@ -19,7 +19,7 @@ from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Sequenc
 
 import numpy as np
 
-from . import ct2, synth
+from . import alignment, ct2, synth
 from .config import (COMPUTE_BF16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
                      WhisperDims)
 from .tokenizer import load_tokenizer
@@ -152,6 +152,15 @@ class WhisperModel:
                 "with model.bin (CTranslate2) or config.json + model.safetensors (HF), or 'synthetic:<preset>' for seeded "
                 "random weights")
         self.dims = dims
+        # word timestamps: curated (layer, head) pairs from the model directory when it has them (CTranslate2 config.json
+        # / HF generation_config.json "alignment_heads"), else the capped last-half-of-the-decoder default
+        heads = self.ct2_config.get("alignment_heads")
+        if heads is None and os.path.isdir(model_size_or_path):
+            gc_path = os.path.join(model_size_or_path, "generation_config.json")
+            if os.path.exists(gc_path):
+                with open(gc_path, "r", encoding="utf-8") as f:
+                    heads = json.load(f).get("alignment_heads")
+        self.alignment_heads = [tuple(h) for h in heads] if heads else alignment.default_alignment_heads(dims.dec_layers, dims.n_heads)
         self.engine = Engine(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
         self.engine.load_weights(tensors)
         self.special = self.engine.special
@@ -260,8 +269,6 @@ class WhisperModel:
             beam_size = 1
         if vad_filter:
             warnings.warn("vad_filter=True: no VAD model in this build, the whole clip is treated as speech", stacklevel=2)
-        if word_timestamps:
-            warnings.warn("word_timestamps=True is not implemented: segments carry words=None", stacklevel=2)
         duration = len(audio) / SAMPLE_RATE
         if language is None:
             if self.is_multilingual:
@@ -279,12 +286,12 @@ class WhisperModel:
                                        without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
                                        max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0),
                                        tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),),
-                                       best_of, compression_ratio_threshold), info
+                                       best_of, compression_ratio_threshold, bool(word_timestamps)), info
 
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
                            no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,
-                           patience=1.0, temperatures=(0.0,), best_of=5, compression_ratio_threshold=2.4
-                           ) -> Iterator[Segment]:
+                           patience=1.0, temperatures=(0.0,), best_of=5, compression_ratio_threshold=2.4,
+                           word_timestamps=False) -> Iterator[Segment]:
         eng, st = self.engine, self.special
         lang_tok = self._lang_token(language)
         n_total = int(np.ceil(len(audio) / HOP)) if len(audio) else 0
@@ -340,12 +347,26 @@ class WhisperModel:
                 continue
             segs, advance = self._split_segments(toks, seek, win_frames, time_offset, without_timestamps)
             limit = time_offset + win_frames * HOP / SAMPLE_RATE  # never report times past the audio that exists
+            kept = []
             for (s0, s1, stoks) in segs:
                 text = self.tokenizer.decode([t for t in stoks if t < st.eot])
                 s0, s1 = min(s0, limit), min(s1, limit)
                 if s0 >= s1 or not text.strip():
                     continue
-                yield Segment(idx, seek, round(s0, 3), round(s1, 3), text, list(stoks), temp_used, avg_lp, cr, ns, None)
+                kept.append(dict(start=s0, end=s1, tokens=list(stoks), text=text, eot=st.eot, words=None))
+            if word_timestamps and kept:
+                # faster-whisper add_word_timestamps: one alignment pass over the window's text tokens (the encoder
+                # state of this window is still resident), then words are dealt to the segments
+                text_tokens = [t for seg in kept for t in seg["tokens"] if t < st.eot]
+                task_tok = st.translate if task == "translate" else st.transcribe
+                found = alignment.find_alignment(eng, self.tokenizer, st, 0, text_tokens, win_frames, self.alignment_heads,
+                                                 language, lang_tok, task_tok)
+                alignment.add_word_timestamps(kept, found, time_offset)
+                for seg in kept:
+                    seg["start"], seg["end"] = min(seg["start"], limit), min(seg["end"], limit)
+            for seg in kept:
+                yield Segment(idx, seek, round(seg["start"], 3), round(seg["end"], 3), seg["text"], seg["tokens"], temp_used,
+                              avg_lp, cr, ns, seg["words"])
                 idx += 1
             prev.extend(t for t in toks if t < st.eot)
             if not condition or temp_used > 0.5:  # faster-whisper: prompt_reset_on_temperature = 0.5
