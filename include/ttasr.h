@@ -121,8 +121,8 @@ int ttasr_generate(ttasr_ctx* ctx, int32_t B, const int32_t* prompt_host, const 
                    int32_t max_prompt, const ttasr_gen_opts* opts, int32_t* out_tokens_host, int32_t* out_len_host,
                    float* out_sum_logprob_host, float* out_no_speech_host);
 /* Beam search (the reference call sites pass beam_size=5: asr_core.py:164, file_asr.py:462,
- * faster_whisper_asr.py:144).  n_audio clips x `beam` hypotheses = rows of the decode batch (<= max_batch, and
- * <= 32 for the bf16 fast path); the `beam` rows of a clip share its cross-attention K/V, and a re-index of the
+ * faster_whisper_asr.py:144).  n_audio clips x `beam` hypotheses = rows of the decode batch (<= max_batch; the bf16
+ * weight-streaming GEMM carries up to 128 rows); the `beam` rows of a clip share its cross-attention K/V, and a re-index of the
  * hypotheses permutes the self-attention page tables (copy-on-write of the one partially filled page) instead
  * of copying caches.  prompt_host: [n_audio][prompt_len] (same length for every clip).  Candidate selection
  * follows Whisper's published beam search (top beam+1 per hypothesis, EOT hypotheses go to a finished pool of

@@ -47,88 +47,110 @@ void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, in
                      row_offset);
 }
 
-template <int NW>  // NW waves per workgroup, each owning steps_per_wave k-steps of 16
+// NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
+// fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
+// which is what amortises the per-step latency when more clips are in flight).
+template <int NW, int RB>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
                                                               int B, int N, int K, int ksplit, GemmEpi e) {
-  constexpr int U = 10;  // k-steps in flight per wave (all of them for the Whisper shapes)
-  __shared__ __attribute__((aligned(16))) float red[NW][32 * 32];  // [wave][b*32 + n]
+  constexpr int U = RB == 1 ? 10 : (RB == 2 ? 8 : 5);  // k-steps in flight per wave (register budget: U * (1 + RB) * 4)
+  __shared__ __attribute__((aligned(16))) float red[NW][RB][32 * 32];  // [wave][row group][b*32 + n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
   const int ks_per = K / 16;
   const int steps = ks_per / (NW * ksplit);
   const int k0 = (ks * NW + wave) * steps;
   const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * ks_per + k0) * 64 + lane;
-  const bf16_t* xp = x + (int64_t)min(lane & 31, B - 1) * K + k0 * 16 + 8 * (lane >> 5);
-  // epilogue operands of this thread's 4 cells (b = tid>>3, n = nb*32 + 4*(tid&7) ..+3), requested now
-  const int eb = min(tid >> 3, B - 1), en = nb * 32 + 4 * (tid & 7);
-  float4 ebias = make_float4(0.f, 0.f, 0.f, 0.f), eres = ebias;
+  const bf16_t* xp[RB];
+#pragma unroll
+  for (int g = 0; g < RB; ++g) xp[g] = x + (int64_t)min(g * 32 + (lane & 31), B - 1) * K + k0 * 16 + 8 * (lane >> 5);
+  // epilogue operands of this thread's 4 cells per row group (b = 32g + tid>>3, n = nb*32 + 4*(tid&7) ..+3), requested now
+  const int en = nb * 32 + 4 * (tid & 7);
+  float4 ebias = make_float4(0.f, 0.f, 0.f, 0.f), eres[RB];
+#pragma unroll
+  for (int g = 0; g < RB; ++g) eres[g] = ebias;
   if (tid < 256 && en + 3 < N) {
     if (e.bias && (ksplit == 1 || ks == 0)) ebias = *(const float4*)(e.bias + en);
-    if (e.residual && ksplit == 1) eres = *(const float4*)(e.residual + (int64_t)eb * e.ldc + en);
-  }
-  f32x16 acc;
+    if (e.residual && ksplit == 1) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+      for (int g = 0; g < RB; ++g) eres[g] = *(const float4*)(e.residual + (int64_t)min(g * 32 + (tid >> 3), B - 1) * e.ldc + en);
+    }
+  }
+  f32x16 acc[RB];
+#pragma unroll
+  for (int g = 0; g < RB; ++g)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[g][j] = 0.f;
   for (int i0 = 0; i0 < steps; i0 += U) {
-    u32x4 w[U], xv[U];
+    u32x4 w[U], xv[RB][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = min(i0 + u, steps - 1);  // clamped and unconditional: nothing branches around a load
       w[u] = wp[(int64_t)i * 64];
-      xv[u] = *(const u32x4*)(xp + i * 16);
+#pragma unroll
+      for (int g = 0; g < RB; ++g) xv[g][u] = *(const u32x4*)(xp[g] + i * 16);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (i0 + u < steps) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[u], acc, 0, 0, 0);
+      if (i0 + u < steps) {
+#pragma unroll
+        for (int g = 0; g < RB; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g], 0, 0, 0);
+      }
   }
   // D: col = lane & 31 = batch row b, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output n
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    *(float4*)&red[wave][(lane & 31) * 32 + 8 * g + 4 * (lane >> 5)] =
-        make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+  for (int g = 0; g < RB; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(float4*)&red[wave][g][(lane & 31) * 32 + 8 * q + 4 * (lane >> 5)] =
+          make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
   __syncthreads();
   if (tid >= 256) return;
-  float4 v = *(const float4*)&red[0][(tid >> 3) * 32 + 4 * (tid & 7)];
 #pragma unroll
-  for (int w = 1; w < NW; ++w) {
-    const float4 t = *(const float4*)&red[w][(tid >> 3) * 32 + 4 * (tid & 7)];
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-  }
-  v.x += ebias.x; v.y += ebias.y; v.z += ebias.z; v.w += ebias.w;
-  const int b = tid >> 3;
-  if (b >= B) return;
-  float vv[4] = {v.x, v.y, v.z, v.w};
-  const float rr[4] = {eres.x, eres.y, eres.z, eres.w};
-  const int64_t idx0 = (int64_t)b * e.ldc + en;
-  if (en + 3 < N && ksplit == 1) {  // full 4-column cell: vector stores
+  for (int g = 0; g < RB; ++g) {
+    float4 v = *(const float4*)&red[0][g][(tid >> 3) * 32 + 4 * (tid & 7)];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+      const float4 t = *(const float4*)&red[w][g][(tid >> 3) * 32 + 4 * (tid & 7)];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    v.x += ebias.x; v.y += ebias.y; v.z += ebias.z; v.w += ebias.w;
+    const int b = g * 32 + (tid >> 3);
+    if (b >= B) continue;
+    float vv[4] = {v.x, v.y, v.z, v.w};
+    const float rr[4] = {eres[g].x, eres[g].y, eres[g].z, eres[g].w};
+    const int64_t idx0 = (int64_t)b * e.ldc + en;
+    if (en + 3 < N && ksplit == 1) {  // full 4-column cell: vector stores
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (e.act == 1) vv[j] = gelu_erf(vv[j]);
+        if (e.residual) vv[j] += rr[j];
+      }
+      if (e.out_f32) *(float4*)(e.out_f32 + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (e.out_t) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(vv[0]) | ((uint32_t)f2bf(vv[1]) << 16);
+        pk.y = (uint32_t)f2bf(vv[2]) | ((uint32_t)f2bf(vv[3]) << 16);
+        *(uint2*)((bf16_t*)e.out_t + idx0) = pk;
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (e.act == 1) vv[j] = gelu_erf(vv[j]);
-      if (e.residual) vv[j] += rr[j];
-    }
-    if (e.out_f32) *(float4*)(e.out_f32 + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    if (e.out_t) {
-      uint2 pk;
-      pk.x = (uint32_t)f2bf(vv[0]) | ((uint32_t)f2bf(vv[1]) << 16);
-      pk.y = (uint32_t)f2bf(vv[2]) | ((uint32_t)f2bf(vv[3]) << 16);
-      *(uint2*)((bf16_t*)e.out_t + idx0) = pk;
-    }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = en + j;
-    if (n < N) {
-      const int64_t idx = idx0 + j;
-      if (ksplit > 1) {
-        atomicAdd(e.out_f32 + idx, vv[j]);  // accumulate into the f32 residual stream
-      } else {
-        float o = vv[j];
-        if (e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
-        if (e.act == 1) o = gelu_erf(o);
-        if (e.residual) o += e.residual[idx];
-        if (e.out_f32) e.out_f32[idx] = o;
-        if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(o);
+      const int n = en + j;
+      if (n < N) {
+        const int64_t idx = idx0 + j;
+        if (ksplit > 1) {
+          atomicAdd(e.out_f32 + idx, vv[j]);  // accumulate into the f32 residual stream
+        } else {
+          float o = vv[j];
+          if (e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
+          if (e.act == 1) o = gelu_erf(o);
+          if (e.residual) o += e.residual[idx];
+          if (e.out_f32) e.out_f32[idx] = o;
+          if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(o);
+        }
       }
     }
   }
@@ -138,26 +160,37 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
 // trip) and the grid has a few hundred workgroups.  Only residual GEMMs (x += W h + b) may split K across
 // workgroups.  Returns false when the shape does not fit (caller falls back to gemm_basic).
 bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s) {
-  if (B < 1 || B > 32 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
+  if (B < 1 || B > 128 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
+  const int rb = (B + 31) / 32;  // 32-row groups sharing one weight stream
   const int n_blocks = (N + 31) / 32;
   const int ks_per = K / 16;
   const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t;
+  const int u = rb == 1 ? 10 : (rb == 2 ? 8 : 5);  // k-steps a wave keeps in flight (kernel's U)
   int nw = 4, ksplit = 1;
   if (can_split) {
     // 8 waves first (LDS reduce is cheaper than contended atomics), then split K across workgroups until a
     // wave owns <= 10 k-steps; keep at least ~160 workgroups when the shape allows
     if (ks_per >= 160 && ks_per % 8 == 0) nw = 8;  // long K (fc2): fewer, fatter workgroups = half the atomics
-    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 10) ksplit *= 2;
+    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > u) ksplit *= 2;
     while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 5 && n_blocks * ksplit < 160) ksplit *= 2;
   } else {
-    while (nw < 16 && ks_per % (nw * 2) == 0 && ks_per / nw > 10) nw *= 2;
+    const int nw_max = rb == 1 ? 16 : 8;  // 16 waves leave 128 VGPRs per lane: only the single row group fits
+    while (nw < nw_max && ks_per % (nw * 2) == 0 && ks_per / nw > u) nw *= 2;
     if (nw < 8 && ks_per % 8 == 0 && ks_per / 8 >= 5 && n_blocks < 256) nw = 8;
   }
-  if (const char* f = getenv("TTASR_SKINNY_NW")) { if (!can_split) nw = atoi(f); }  // tuning experiments
+  if (const char* f = getenv("TTASR_SKINNY_NW")) { if (!can_split && rb == 1) nw = atoi(f); }  // tuning experiments
   if (ks_per % (nw * ksplit) != 0) return false;
   dim3 grid(n_blocks, ksplit);
-  if (nw == 16) hipLaunchKernelGGL(gemm_skinny_kernel<16>, grid, dim3(1024), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else if (nw == 8) hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, dim3(512), 0, s, Wsh, x, B, N, K, ksplit, e);
-  else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, s, Wsh, x, B, N, K, ksplit, e);
+#define TTASR_SKINNY(NW_, RB_) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e)
+  if (rb == 1) {
+    if (nw == 16) TTASR_SKINNY(16, 1); else if (nw == 8) TTASR_SKINNY(8, 1); else TTASR_SKINNY(4, 1);
+  } else if (rb == 2) {
+    if (nw == 8) TTASR_SKINNY(8, 2); else TTASR_SKINNY(4, 2);
+  } else if (rb == 3) {
+    if (nw == 8) TTASR_SKINNY(8, 3); else TTASR_SKINNY(4, 3);
+  } else {
+    if (nw == 8) TTASR_SKINNY(8, 4); else TTASR_SKINNY(4, 4);
+  }
+#undef TTASR_SKINNY
   return true;
 }
