@@ -19,7 +19,7 @@ from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Sequenc
 
 import numpy as np
 
-from . import alignment, ct2, synth
+from . import alignment, ct2, synth, vad
 from .config import (COMPUTE_BF16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
                      WhisperDims)
 from .tokenizer import load_tokenizer
@@ -135,6 +135,7 @@ class WhisperModel:
         self.device = "cuda"
         self.compute_type = compute_type
         self.ct2_config: dict = {}
+        self.vad_speech_prob_fn = None   # operator hook: audio f32[n] -> speech probability per 512-sample frame (e.g. Silero ONNX)
         if os.path.isdir(model_size_or_path) and ct2.is_ct2_dir(model_size_or_path):
             # the deployed format (CTranslate2 model.bin; faster_whisper_asr.py:38) -- reader is unpinned, see ct2.py
             dims, tensors, self.ct2_config = ct2.read_ct2_dir(model_size_or_path)
@@ -267,9 +268,27 @@ class WhisperModel:
             warnings.warn(f"beam_size={beam_size} exceeds this model's row budget (max_batch={self.max_batch}, kernel limit 7): "
                           "decoding greedily", stacklevel=2)
             beam_size = 1
+        chunks = None
         if vad_filter:
-            warnings.warn("vad_filter=True: no VAD model in this build, the whole clip is treated as speech", stacklevel=2)
-        duration = len(audio) / SAMPLE_RATE
+            # faster-whisper: Silero VAD -> speech chunks -> transcribe their concatenation -> restore the time line.
+            # The network is not available offline: with a speech-probability function supplied by the operator
+            # (`vad_speech_prob_fn=` here or `model.vad_speech_prob_fn`), or with the explicit opt-in
+            # vad_parameters={"backend": "energy"}, the full pipeline runs; otherwise the whole clip counts as speech.
+            params = dict(kwargs.get("vad_parameters") or {})
+            backend = params.pop("backend", None)
+            prob_fn = kwargs.get("vad_speech_prob_fn") or self.vad_speech_prob_fn
+            if prob_fn is None and backend != "energy":
+                warnings.warn("vad_filter=True: the Silero VAD network is not available in this build and no "
+                              "vad_speech_prob_fn was given; the whole clip is treated as speech", stacklevel=2)
+            else:
+                if prob_fn is None:
+                    warnings.warn("vad_filter=True with the short-time-energy stand-in (NOT equivalent to Silero VAD)",
+                                  stacklevel=2)
+                chunks = vad.get_speech_timestamps(audio, vad.VadOptions(**params), prob_fn)
+                audio_full_len = len(audio)
+                audio = vad.collect_chunks(audio, chunks)
+        duration_after_vad = len(audio) / SAMPLE_RATE
+        duration = (audio_full_len if chunks is not None else len(audio)) / SAMPLE_RATE
         if language is None:
             if self.is_multilingual:
                 language, lang_p, all_p = self.detect_language(audio)
@@ -278,15 +297,18 @@ class WhisperModel:
         else:
             lang_p, all_p = 1.0, None
         info = TranscriptionInfo(language=language, language_probability=lang_p, duration=duration,
-                                 duration_after_vad=duration, all_language_probs=all_p,
+                                 duration_after_vad=duration_after_vad, all_language_probs=all_p,
                                  transcription_options=dict(beam_size=beam_size, task=task, without_timestamps=without_timestamps,
                                                             condition_on_previous_text=condition_on_previous_text,
                                                             initial_prompt=initial_prompt))
-        return self._generate_segments(audio, language, task, condition_on_previous_text, initial_prompt,
-                                       without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
-                                       max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0),
-                                       tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),),
-                                       best_of, compression_ratio_threshold, bool(word_timestamps)), info
+        segments = self._generate_segments(audio, language, task, condition_on_previous_text, initial_prompt,
+                                           without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
+                                           max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0),
+                                           tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),),
+                                           best_of, compression_ratio_threshold, bool(word_timestamps))
+        if chunks is not None:
+            segments = vad.restore_speech_timestamps(segments, chunks)
+        return segments, info
 
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
                            no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,

@@ -166,3 +166,36 @@ def test_ct2_directory_loads_like_the_same_weights_in_memory(tmp_path):
     final = batch_cli.process_audio_folder(str(folder), model=m, output_json=str(tmp_path / "out.json"), log=lambda *_: None)
     assert final["summary"]["total_files"] == 1 and "error" not in final["detailed_results"][0]
     assert (folder / "a_asr.txt").exists()
+
+
+def test_vad_filter_pipeline_with_the_energy_stand_in(model):
+    """vad_filter=True + a speech-probability source: only the speech chunks reach the engine and every time comes
+    back on the original time line (two bursts 10 s apart -> the second segment group is shifted by the removed pause)."""
+    from taiwan_tongues_asr_ce_amd import vad
+    a = np.zeros(30 * 16000, np.float32)
+    a[: 4 * 16000] = synth.tonal_clip(0)[: 4 * 16000]
+    a[14 * 16000: 18 * 16000] = synth.tonal_clip(1)[: 4 * 16000]
+    chunks = vad.get_speech_timestamps(a, vad.VadOptions())
+    assert len(chunks) == 2 and chunks[1]["start"] > 13 * 16000
+    kw = dict(language="zh", beam_size=1, temperature=0.0, max_new_tokens=24)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        segs, info = model.transcribe(a, vad_filter=True, vad_parameters={"backend": "energy"}, **kw)
+        segs = list(segs)
+        assert any("stand-in" in str(x.message) for x in w)
+    cut = vad.collect_chunks(a, chunks)
+    ref, ref_info = model.transcribe(cut, vad_filter=False, **kw)
+    ref = list(ref)
+    assert abs(info.duration - 30.0) < 1e-6 and abs(info.duration_after_vad - len(cut) / 16000) < 1e-6 < info.duration_after_vad < 10
+    assert [s.tokens for s in segs] == [s.tokens for s in ref] and len(segs) > 0
+    m = vad.SpeechTimestampsMap(chunks)
+    for s, r in zip(segs, ref):
+        assert s.start == m.get_original_time(r.start) and s.end == m.get_original_time(r.end)
+    assert all(s.end <= 18.5 for s in segs) and all(not (4.5 < s.start < 13.5) for s in segs)
+    # an operator-supplied probability function takes precedence and needs no opt-in
+    model.vad_speech_prob_fn = lambda audio: np.zeros(int(np.ceil(len(audio) / vad.WINDOW)), np.float32)
+    try:
+        segs, info = model.transcribe(a, vad_filter=True, **kw)
+        assert list(segs) == [] and info.duration_after_vad == 0.0
+    finally:
+        model.vad_speech_prob_fn = None

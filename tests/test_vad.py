@@ -1,0 +1,84 @@
+"""VAD plumbing around the (absent) Silero network: chunking state machine, chunk collection, time restoration.
+Expected values are derived by hand from the published rule (see the comments); the module is unpinned."""
+from typing import NamedTuple, Optional, List
+
+import numpy as np
+import pytest
+
+from taiwan_tongues_asr_ce_amd import synth, vad
+
+W = vad.WINDOW
+
+
+def _probs(*runs):
+    """runs of (n_frames, probability) -> (audio placeholder of the right length, prob function)"""
+    p = np.concatenate([np.full(n, v, np.float32) for n, v in runs])
+    return np.zeros(len(p) * W, np.float32), (lambda audio: p)
+
+
+def test_two_utterances_with_a_long_pause():
+    audio, fn = _probs((10, 0.0), (50, 0.9), (100, 0.0), (30, 0.9))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(), fn)
+    # speech 1: frames 10..59 -> [5120, 30720); the pause reaches 2 s at frame 123 -> closed at its beginning.
+    # speech 2: frames 160..189, open at the end of the audio -> [81920, 97280).  Pads of 6400 samples, gap 51200 >= 12800.
+    assert got == [{"start": 0, "end": 37120}, {"start": 75520, "end": 97280}]
+    assert len(vad.collect_chunks(audio, got)) == 37120 + 21760
+
+
+def test_short_pause_does_not_split_and_blips_are_dropped():
+    audio, fn = _probs((5, 0.0), (40, 0.8), (30, 0.1), (40, 0.8), (70, 0.0))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(speech_pad_ms=0), fn)
+    assert got == [{"start": 5 * W, "end": 115 * W}]                      # 30 frames = 0.96 s < 2 s: one chunk
+    audio, fn = _probs((5, 0.0), (5, 0.9), (80, 0.0), (40, 0.9), (70, 0.0))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(min_speech_duration_ms=250, speech_pad_ms=0), fn)
+    assert got == [{"start": 90 * W, "end": 130 * W}]                    # the 160-ms blip is below 250 ms
+    # hysteresis: probabilities between neg_threshold (0.35) and threshold (0.5) neither open nor close a chunk
+    audio, fn = _probs((5, 0.4), (20, 0.9), (80, 0.4), (5, 0.0))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(speech_pad_ms=0), fn)
+    assert got == [{"start": 5 * W, "end": 110 * W}]
+
+
+def test_close_chunks_share_the_gap_and_long_speech_is_cut_at_a_pause():
+    audio, fn = _probs((20, 0.9), (20, 0.0), (20, 0.9))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(min_silence_duration_ms=500), fn)
+    # closes after 500 ms (frame 36); gap 10240 samples < 2 * 6400 -> each side takes half
+    assert got == [{"start": 0, "end": 20 * W + 5120}, {"start": 40 * W - 5120, "end": 60 * W}]
+    audio, fn = _probs((40, 0.9), (5, 0.1), (55, 0.9))
+    got = vad.get_speech_timestamps(audio, vad.VadOptions(max_speech_duration_s=2.0, speech_pad_ms=0), fn)
+    # 2 s = 61.5 frames is exceeded at frame 62; the last pause >= 98 ms began at frame 40, speech resumed at 45
+    assert got == [{"start": 0, "end": 40 * W}, {"start": 45 * W, "end": 100 * W}]
+    assert vad.get_speech_timestamps(*_probs((50, 0.1))[:1], vad.VadOptions(), _probs((50, 0.1))[1]) == []
+
+
+def test_time_restoration():
+    chunks = [{"start": 0, "end": 37120}, {"start": 75520, "end": 97280}]
+    m = vad.SpeechTimestampsMap(chunks)
+    assert m.chunk_end_sample == [37120, 58880] and m.total_silence_before == [0.0, 2.4]
+    assert m.get_original_time(1.0) == 1.0 and m.get_original_time(2.5) == 4.9 and m.get_original_time(3.68) == 6.08
+
+    class Wd(NamedTuple):
+        start: float
+        end: float
+        word: str
+        probability: float
+
+    class Seg(NamedTuple):
+        start: float
+        end: float
+        text: str
+        words: Optional[List[Wd]]
+
+    segs = [Seg(0.5, 2.0, "a", None), Seg(2.4, 3.0, "b", [Wd(2.3, 2.5, "x", 0.9), Wd(2.5, 3.0, "y", 0.8)])]
+    out = list(vad.restore_speech_timestamps(iter(segs), chunks))
+    assert (out[0].start, out[0].end) == (0.5, 2.0)
+    # word x straddles the cut (2.32 s): its middle (2.4) lies in chunk 2 -> both ends move by 2.4 s
+    assert [(w.start, w.end) for w in out[1].words] == [(4.7, 4.9), (4.9, 5.4)] and (out[1].start, out[1].end) == (4.7, 5.4)
+
+
+def test_energy_stand_in_finds_the_burst():
+    clip = synth.burst_clip(0)                      # 3 s of noise, then zeros
+    p = vad.energy_speech_prob(clip)
+    n_loud = 3 * 16000 // W
+    assert p[: n_loud - 1].min() > 0.9 and p[n_loud + 1:].max() < 0.1
+    got = vad.get_speech_timestamps(clip, vad.VadOptions())
+    assert len(got) == 1 and got[0]["start"] == 0 and abs(got[0]["end"] - (3 * 16000 + 6400)) <= W
