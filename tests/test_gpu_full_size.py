@@ -85,3 +85,44 @@ def test_full_size_invariants(eng):
     e.encode(3)
     beam1 = e.generate_beam([prompt] * 3, 1, e.gen_opts(16, True, suppress_eot=True))
     assert _same_prefix_fraction(beam1.tokens, solo_rows, 4) >= 2 / 3
+
+
+def test_full_depth_f32_parity_one_clip():
+    """The north-star tolerance at the FULL model: whisper-large-v3 geometry, all 32 + 32 layers, f32 compute mode,
+    one 30-s clip — encoder output and the logits of the prompt positions within 1e-3 of the f32 CPU oracle, greedy
+    tokens identical.  (~3 TFLOP on the host cores for the oracle, hence a single clip and three new tokens.)"""
+    import torch
+    from oracle import whisper_ref as R
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_F32
+    from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
+    torch.set_grad_enabled(False)
+    dims = PRESETS["large-v3"]
+    rd = R.Dims(**dims.as_dict())
+    sd = synth.state_dict(dims)
+    e = Engine(dims, COMPUTE_F32, 1)
+    e.load_weights(sd.items())
+    st = e.special
+    clip = synth.tonal_clip(2)
+    mel = e.log_mel([clip])
+    enc = e.encode(1, want_output=True)
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    e.decode_reset(1)
+    step_logits = [e.decode_step([t]) for t in prompt]
+    opts = e.gen_opts(3, False)
+    res = e.generate([prompt], opts)
+    e.close()
+    W = R.to_torch(sd)
+    del sd
+    mel_ref = R.log_mel(clip, dims.n_mels)[None]
+    np.testing.assert_allclose(mel, mel_ref, atol=2e-4)
+    enc_ref = R.encoder_forward(torch.from_numpy(mel_ref), W, rd)
+    assert float(np.abs(enc - enc_ref.numpy()).max()) < 1e-3
+    xkv = R.cross_kv(enc_ref, W, rd)
+    cache = R.SelfCache.empty(rd.dec_layers)
+    for t, lg in zip(prompt, step_logits):
+        want = R.decoder_forward(torch.full((1, 1), t), cache, xkv, W, rd)[:, 0].numpy()
+        assert float(np.abs(lg - want).max()) < 1e-3
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False)
+    ref = R.greedy_decode(enc_ref, prompt, W, rd, rules, 3)
+    assert res.tokens == ref.tokens
