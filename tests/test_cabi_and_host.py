@@ -156,3 +156,42 @@ def test_streaming_trigger_rule_table():
                                    (3.0, 3.0, True), (1.5, 1.0, True), (1.5, 1.39, True), (1.5, 1.41, False),
                                    (0.5, 0.0, True), (0.05, 0.0, False)]:
         assert should_transcribe(int(round(seconds * bps)), vad_end, off) == want, (seconds, vad_end)
+
+
+def test_hf_directory_reader_safetensors_and_bin(tmp_path):
+    """The HF-format `models/` directory (config.json + model.safetensors | pytorch_model.bin): geometry from the config,
+    every tensor back as float32 under its HF name, the tied proj_out dropped."""
+    import json
+    import torch
+    from safetensors.numpy import save_file
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.model import _read_hf_dir
+    d = PRESETS["micro"]
+    sd = synth.state_dict(d)
+    cfg = dict(num_mel_bins=d.n_mels, max_source_positions=d.n_audio_ctx, d_model=d.d_model, encoder_attention_heads=d.n_heads,
+               encoder_ffn_dim=d.ffn_dim, encoder_layers=d.enc_layers, decoder_layers=d.dec_layers, vocab_size=d.vocab,
+               max_target_positions=d.n_text_ctx)
+    for kind in ("safetensors", "bin"):
+        p = tmp_path / kind
+        p.mkdir()
+        (p / "config.json").write_text(json.dumps(cfg), encoding="utf-8")
+        full = dict(sd)
+        full["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+        if kind == "safetensors":
+            save_file({k: v.astype(np.float16) for k, v in full.items()}, str(p / "model.safetensors"))   # fp16 checkpoint
+        else:
+            torch.save({k: torch.from_numpy(v) for k, v in full.items()}, str(p / "pytorch_model.bin"))
+        dims, tensors = _read_hf_dir(str(p))
+        assert (dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, dims.enc_layers, dims.dec_layers,
+                dims.vocab, dims.n_text_ctx) == (d.n_mels, d.n_audio_ctx, d.d_model, d.n_heads, d.ffn_dim, d.enc_layers,
+                                                 d.dec_layers, d.vocab, d.n_text_ctx)
+        got = dict(tensors)
+        assert set(got) == set(sd)
+        for k, v in sd.items():
+            assert got[k].dtype == np.float32
+            ref = v.astype(np.float16).astype(np.float32) if kind == "safetensors" else v
+            assert np.array_equal(got[k], ref), k
+    with pytest.raises(FileNotFoundError):
+        (tmp_path / "empty").mkdir()
+        (tmp_path / "empty" / "config.json").write_text(json.dumps(cfg), encoding="utf-8")
+        list(_read_hf_dir(str(tmp_path / "empty"))[1])

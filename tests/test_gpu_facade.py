@@ -199,3 +199,34 @@ def test_vad_filter_pipeline_with_the_energy_stand_in(model):
         assert list(segs) == [] and info.duration_after_vad == 0.0
     finally:
         model.vad_speech_prob_fn = None
+
+
+def test_hf_directory_with_generation_config_alignment_heads(tmp_path):
+    """WhisperModel on an HF-format directory (fp16 safetensors, generation_config.json with curated alignment heads):
+    same tokens as the identical weights loaded in memory; word timestamps use the directory's heads."""
+    import json
+    from safetensors.numpy import save_file
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    d = PRESETS["micro"]
+    hf = {k: v.astype(np.float16) for k, v in synth.iter_weights(d)}
+    (tmp_path / "config.json").write_text(json.dumps(dict(
+        num_mel_bins=d.n_mels, max_source_positions=d.n_audio_ctx, d_model=d.d_model, encoder_attention_heads=d.n_heads,
+        encoder_ffn_dim=d.ffn_dim, encoder_layers=d.enc_layers, decoder_layers=d.dec_layers, vocab_size=d.vocab,
+        max_target_positions=d.n_text_ctx)), encoding="utf-8")
+    (tmp_path / "generation_config.json").write_text(json.dumps({"alignment_heads": [[1, 0], [1, 1]]}), encoding="utf-8")
+    save_file(hf, str(tmp_path / "model.safetensors"))
+    m = WhisperModel(str(tmp_path), device="cuda", compute_type="float32", max_batch=2)
+    assert m.alignment_heads == [(1, 0), (1, 1)]
+    clip = synth.noise_clip(4)[: d.n_frames * 160]
+    eng = m.engine
+    eng.log_mel([clip], want_output=False)
+    enc = eng.encode(1, want_output=True)
+    W = R.to_torch({k: v.astype(np.float32) for k, v in hf.items()})
+    rd = R.Dims(**d.as_dict())
+    enc_ref = R.encoder_forward(torch.from_numpy(R.log_mel(clip, d.n_mels, n_samples=d.n_frames * 160))[None], W, rd).numpy()
+    assert np.abs(enc - enc_ref).max() < 1e-3
+    st = m.special
+    toks = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps, 7, 9, 11, 13, st.eot]
+    w, lp = eng.align(0, toks, m.alignment_heads)
+    rw, rlp = R.alignment_weights(torch.from_numpy(enc_ref), toks, W, rd, m.alignment_heads, return_logprobs=True)
+    assert np.abs(w - rw.numpy()).max() < 2e-5 and np.abs(lp - rlp.numpy()).max() < 2e-3
