@@ -1,0 +1,104 @@
+"""GPU: seeded differential fuzzing of the f32 engine against the CPU oracle on the micro model (where the oracle
+costs milliseconds): random batch sizes, ragged prompts with and without a previous-text prefix (prefill path),
+random rule sets, audio windows, greedy / beam / sampled decoding.  Every case must match the oracle token for token."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_F32, PRESETS
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+NAME = "micro"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    pd = PRESETS[NAME]
+    e = Engine(pd, COMPUTE_F32, 8)
+    e.load_weights(synth.iter_weights(pd))
+    W = R.to_torch(synth.state_dict(pd))
+    yield e, pd, R.Dims(**pd.as_dict()), W
+    e.close()
+
+
+def _clips(rng, B, n_ctx):
+    n = n_ctx * 320
+    out = []
+    for _ in range(B):
+        kind = rng.integers(0, 4)
+        length = int(rng.integers(n // 3, n + 1)) if kind != 3 else 0
+        c = (0.1 * rng.standard_normal(length)).astype(np.float32)
+        if kind == 1 and length:
+            c[length // 2:] = 0.0
+        out.append(c)
+    return out
+
+
+import os as _os
+
+
+@pytest.mark.parametrize("seed", range(int(_os.environ.get("TTASR_FUZZ_CASES", "24"))))
+def test_random_configuration_matches_oracle(ctx, seed):
+    e, pd, dims, W = ctx
+    st = e.special
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 9))
+    n_ctx = int(rng.choice([pd.n_audio_ctx, pd.n_audio_ctx, 20, 36]))
+    e.set_audio_ctx(n_ctx if n_ctx != pd.n_audio_ctx else 0)
+    clips = _clips(rng, B, n_ctx)
+    mel = e.log_mel(clips)
+    want_mel = np.stack([R.log_mel(c, pd.n_mels, n_samples=n_ctx * 320) for c in clips])
+    np.testing.assert_allclose(mel, want_mel, atol=3e-4, rtol=0)
+    enc = e.encode(B, want_output=True)
+    enc_ref = R.encoder_forward(torch.from_numpy(want_mel), W, dims)
+    assert np.abs(enc - enc_ref.numpy()).max() < 1e-3
+    timestamps = bool(rng.integers(0, 2))
+    text_hi = st.eot
+    suppress = sorted(set(rng.integers(0, text_hi, size=int(rng.integers(0, 12))).tolist()) | {st.sot, st.sot_prev, st.no_speech})
+    begin_suppress = sorted(set(rng.integers(0, text_hi, size=int(rng.integers(0, 3))).tolist()) | {st.eot})
+    tail = [st.sot, st.lang_zh, st.transcribe] + ([] if timestamps else [st.no_timestamps])
+    mode = ["greedy", "greedy", "beam", "sample"][int(rng.integers(0, 4))]
+    room = pd.n_text_ctx - len(tail) - 2
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=suppress,
+                    begin_suppress=begin_suppress, timestamps=timestamps)
+    if mode == "greedy":
+        # ragged prompts: each row its own previous-text prefix (0..12 tokens) -> exercises prefill + forced steps
+        prompts = []
+        for _ in range(B):
+            n_prev = int(rng.integers(0, min(13, room - 3)))
+            prev = ([st.sot_prev] + rng.integers(0, text_hi, size=n_prev).tolist()) if n_prev else []
+            prompts.append(prev + tail)
+        max_new = int(rng.integers(1, pd.n_text_ctx - max(len(p) for p in prompts)))
+        opts = e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=begin_suppress, no_speech=False,
+                          check_interval=int(rng.integers(1, 5)))
+        res = e.generate(prompts, opts)
+        for b in range(B):
+            ref = R.greedy_decode(enc_ref[b:b + 1], prompts[b], W, dims, rules, max_new)
+            assert res.tokens[b] == ref.tokens[0], (seed, b)
+            assert abs(float(res.sum_logprob[b]) - ref.sum_logprob[0]) < 5e-3 * max(1, len(ref.tokens[0]))
+    else:
+        n_prev = int(rng.integers(0, 10))
+        prev = ([st.sot_prev] + rng.integers(0, text_hi, size=n_prev).tolist()) if n_prev else []
+        prompt = prev + tail
+        sot_index = prompt.index(st.sot)
+        max_new = int(rng.integers(2, pd.n_text_ctx - len(prompt)))
+        opts = e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=begin_suppress, sot_index=sot_index)
+        width = int(rng.integers(2, 5))
+        A = max(1, min(B, 8 // width))
+        if mode == "beam":
+            res = e.generate_beam([prompt] * A, width, opts)
+            ref = R.beam_decode(enc_ref[:A], prompt, W, dims, rules, width, max_new, no_speech_token=st.no_speech, sot_index=sot_index)
+            strip = lambda rows: [[t for t in r if t != st.eot] for r in rows]
+            assert strip(res.tokens) == strip(ref.tokens), seed
+        else:
+            temp, s = float(rng.choice([0.3, 0.7, 1.0])), int(rng.integers(0, 1 << 30))
+            res = e.generate_sample([prompt] * A, width, opts, temperature=temp, seed=s)
+            ref = R.sample_decode(enc_ref[:A], prompt, W, dims, rules, width, temp, s, max_new)
+            assert res.tokens == ref.tokens, seed
+        if mode == "beam":
+            np.testing.assert_allclose(res.no_speech_prob[:A], ref.no_speech_prob[:A], rtol=2e-3, atol=1e-6)
+    e.set_audio_ctx(0)
