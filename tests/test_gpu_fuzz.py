@@ -102,3 +102,54 @@ def test_random_configuration_matches_oracle(ctx, seed):
         if mode == "beam":
             np.testing.assert_allclose(res.no_speech_prob[:A], ref.no_speech_prob[:A], rtol=2e-3, atol=1e-6)
     e.set_audio_ctx(0)
+
+
+@pytest.fixture(scope="module")
+def ctx_bf16():
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    pd = PRESETS["tiny"]
+    e = Engine(pd, COMPUTE_BF16, 40)
+    e.load_weights(synth.iter_weights(pd))
+    Wb = R.to_torch(synth.state_dict(pd), round_bf16=True)
+    yield e, pd, R.Dims(**pd.as_dict()), Wb
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_configuration_bf16_within_tolerance(ctx_bf16, seed):
+    """The measured (bf16) mode over random batch sizes 1..40, windows, prompts with a previous-text prefix and rule
+    sets: under teacher forcing every greedy choice is within 0.15 of the oracle's best allowed logit."""
+    e, pd, dims, Wb = ctx_bf16
+    st = e.special
+    rng = np.random.default_rng(5000 + seed)
+    B = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 40]))
+    n_ctx = int(rng.choice([1500, 1500, 300, 750]))
+    e.set_audio_ctx(n_ctx if n_ctx != 1500 else 0)
+    base = [synth.noise_clip(int(rng.integers(0, 50)), n_ctx * 320), synth.tonal_clip(int(rng.integers(0, 50)))[: n_ctx * 320]]
+    clips = [base[b % 2] for b in range(B)]
+    e.log_mel(clips, want_output=False)
+    e.encode(B)
+    timestamps = bool(rng.integers(0, 2))
+    suppress = sorted(set(rng.integers(0, 50000, size=20).tolist()) | {st.sot, st.sot_prev, st.no_speech, st.transcribe, st.translate})
+    n_prev = int(rng.choice([0, 6, 30]))
+    prev = ([st.sot_prev] + rng.integers(300, 20000, size=n_prev).tolist()) if n_prev else []
+    prompt = prev + [st.sot, st.lang_zh, st.transcribe] + ([] if timestamps else [st.no_timestamps])
+    max_new = int(rng.integers(3, 9))
+    opts = e.gen_opts(max_new, timestamps, suppress=suppress, no_speech=False)
+    res = e.generate([prompt] * B, opts)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=suppress,
+                    begin_suppress=[220, st.eot], timestamps=timestamps)
+    mel = torch.from_numpy(np.stack([R.log_mel(c, pd.n_mels, n_samples=n_ctx * 320) for c in base]))
+    enc = R.encoder_forward(mel, Wb, dims)
+    for b in sorted({0, B - 1, B // 2}):
+        xkv = R.cross_kv(enc[b % 2:b % 2 + 1], Wb, dims)
+        cache = R.SelfCache.empty(dims.dec_layers)
+        logits = R.decoder_forward(torch.tensor([prompt]), cache, xkv, Wb, dims)[:, -1]
+        toks = res.tokens[b]
+        assert len(toks) > 0
+        for i, t in enumerate(toks):
+            s = R.apply_rules(logits[0], toks[:i], rules)
+            assert s[t] > -np.inf and float(s.max() - s[t]) < 0.15, (seed, b, i)
+            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
+    e.set_audio_ctx(0)
