@@ -345,7 +345,9 @@ class WhisperModel:
                     rows = max(1, min(best_of, self.max_batch))
                     res = eng.generate_sample([prompt], rows, opts, temp, seed=(seek * 1000003 + int(temp * 1000)) & 0x7FFFFFFF)
                 toks = res.tokens[0]
-                n_tok = max(len(toks), 1)
+                # faster-whisper: avg_logprob = cum_logprob / (seq_len + 1), seq_len without <|endoftext|> (whose
+                # log-probability is part of the sum): the same divisor whether or not this path returns the EOT
+                n_tok = len([t for t in toks if t != st.eot]) + 1
                 avg_lp = float(res.sum_logprob[0]) / n_tok
                 ns = float(res.no_speech_prob[0])
                 text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
