@@ -392,7 +392,9 @@ class WhisperModel:
                 yield Segment(idx, seek, round(seg["start"], 3), round(seg["end"], 3), seg["text"], seg["tokens"], temp_used,
                               avg_lp, cr, ns, seg["words"])
                 idx += 1
-            prev.extend(t for t in toks if t < st.eot)
+                # faster-whisper's all_tokens: the tokens of every YIELDED segment, timestamp tokens included (the
+                # previous-text prompt carries them), <|endoftext|> and the undecided tail after the last pair excluded
+                prev.extend(t for t in seg["tokens"] if t != st.eot)
             if not condition or temp_used > 0.5:  # faster-whisper: prompt_reset_on_temperature = 0.5
                 prompt_reset = len(prev)  # prompt_reset_since: nothing carries over
             seek += min(advance, win_frames) if advance > 0 else win_frames
