@@ -394,10 +394,12 @@ bool gemm_bf16_v2_ok(const GemmArgs& g) {
          ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
 }
 void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};  // per device, see launch_v3
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 128;
   hipLaunchKernelGGL(gemm_bf16_v2_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 3 * 49152, s, g, tiles_m, tiles_n);
@@ -618,10 +620,14 @@ bool gemm_bf16_v3_ok(const GemmArgs& g) {
 }
 template <int EPI>
 static void launch_v3(const GemmArgs& g, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  // the opt-in to > 64 KB of dynamic LDS is per device: remember it per device (one process normally owns one GPU, but a
+  // host that opens contexts on several must not launch on the second with the first one's flag)
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
   hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
