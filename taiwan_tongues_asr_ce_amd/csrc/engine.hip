@@ -630,6 +630,20 @@ int reset_search(ttasr_ctx* c, int B) {
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
+// No C++ exception may cross the C ABI (std::bad_alloc from a host vector would otherwise terminate the caller's process)
+template <class F>
+static int guarded(ttasr_ctx* c, F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(c, TTASR_E_NOMEM, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(c, TTASR_E_INVALID, "C++ exception: %s", e.what());
+  } catch (...) {
+    return fail(c, TTASR_E_INVALID, "unknown C++ exception");
+  }
+}
+
 extern "C" {
 
 const char* ttasr_version(void) { return "ttasr 0.1 (gfx950, HIP)"; }
@@ -637,6 +651,7 @@ const char* ttasr_version(void) { return "ttasr 0.1 (gfx950, HIP)"; }
 const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
+  return guarded(nullptr, [&]() -> int {
   if (!cfg || !out_ctx) return fail(nullptr, TTASR_E_INVALID, "cfg/out_ctx is NULL");
   *out_ctx = nullptr;
   if (cfg->d_model <= 0 || cfg->n_heads <= 0 || cfg->d_model != cfg->n_heads * 64)
@@ -684,6 +699,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (rc) return die(rc);
   *out_ctx = c.release();
   return TTASR_OK;
+  });
 }
 
 void ttasr_destroy(ttasr_ctx* c) {
@@ -702,6 +718,7 @@ void ttasr_destroy(ttasr_ctx* c) {
 }
 
 int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (!name || !data || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
   if (std::string(name) == "proj_out.weight") return TTASR_OK;  // tied to embed_tokens
@@ -739,18 +756,22 @@ int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const i
   HIPCHK(c, hipStreamSynchronize(c->stream));  // src/tmp are caller/stack owned
   s.loaded = true;
   return TTASR_OK;
+  });
 }
 
 int ttasr_finalize_weights(ttasr_ctx* c) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   for (auto& kv : c->slots)
     if (!kv.second.loaded) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' was never loaded", kv.first.c_str());
   c->finalized = true;
   return TTASR_OK;
+  });
 }
 
 int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int64_t* n_samples, int32_t B,
                   int32_t on_device, float* out_mel) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (B < 1 || B > c->maxB) return fail(c, TTASR_E_INVALID, "batch %d outside [1, %d]", B, c->maxB);
   if (!pcm || !n_samples) return fail(c, TTASR_E_INVALID, "pcm / n_samples is NULL");
@@ -781,9 +802,11 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
   hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);
   c->B_mel = B;
   return TTASR_OK;
+  });
 }
 
 int ttasr_set_mel(ttasr_ctx* c, const float* mel, int32_t B) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (B < 1 || B > c->maxB || !mel) return fail(c, TTASR_E_INVALID, "bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
@@ -794,9 +817,11 @@ int ttasr_set_mel(ttasr_ctx* c, const float* mel, int32_t B) {
   HIPCHK(c, hipGetLastError());
   c->B_mel = B;
   return TTASR_OK;
+  });
 }
 
 int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (c->B_mel < B) return fail(c, TTASR_E_INVALID, "mel for %d clips requested but only %d resident", B, c->B_mel);
   if (c->bf16) run_encoder<bf16_t>(c, B); else run_encoder<float>(c, B);
@@ -812,9 +837,11 @@ int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
   hipEventElapsedTime(&c->phase_ms[2], c->ev[3], c->ev[4]);
   c->B_enc = B;
   return TTASR_OK;
+  });
 }
 
 int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (!enc) return fail(c, TTASR_E_INVALID, "enc is NULL");
   const int64_t n = (int64_t)B * c->T * c->d;
@@ -826,9 +853,11 @@ int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
   HIPCHK(c, hipGetLastError());
   c->B_enc = B;
   return TTASR_OK;
+  });
 }
 
 int ttasr_get_cross_kv(ttasr_ctx* c, int32_t layer, int32_t which, int32_t B, float* out) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (layer < 0 || layer >= c->cfg.dec_layers || which < 0 || which > 1 || !out || B > c->B_enc)
     return fail(c, TTASR_E_INVALID, "bad arguments");
@@ -839,18 +868,22 @@ int ttasr_get_cross_kv(ttasr_ctx* c, int32_t layer, int32_t which, int32_t B, fl
   else HIPCHK(c, hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return TTASR_OK;
+  });
 }
 
 int ttasr_decode_reset(ttasr_ctx* c, int32_t B) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   TRY(reset_search(c, B));
   c->st.prompt = nullptr; c->st.prompt_len = nullptr;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->B_dec = B;
   return TTASR_OK;
+  });
 }
 
 int ttasr_decode_step(ttasr_ctx* c, const int32_t* tokens, int32_t B, float* logits) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (!tokens) return fail(c, TTASR_E_INVALID, "tokens is NULL");
   if (B != c->B_dec || B > c->B_enc) return fail(c, TTASR_E_INVALID, "call ttasr_encode and ttasr_decode_reset(B) first");
@@ -866,6 +899,7 @@ int ttasr_decode_step(ttasr_ctx* c, const int32_t* tokens, int32_t B, float* log
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   return TTASR_OK;
+  });
 }
 
 int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
@@ -944,15 +978,18 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
 
 int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
                    const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (!prompt || !prompt_len || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
   if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
   if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
   return generate_rows(c, B, 1, prompt, prompt_len, max_prompt, o, 0.f, 0, out_tokens, out_len, out_lp, out_ns);
+  });
 }
 
 int ttasr_generate_sample(ttasr_ctx* c, int32_t A, int32_t best_of, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
                           float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (A < 1 || best_of < 1 || !(temperature > 0.f)) return fail(c, TTASR_E_INVALID, "n_audio, best_of >= 1 and temperature > 0 required");
   const int R = A * best_of;
@@ -974,10 +1011,12 @@ int ttasr_generate_sample(ttasr_ctx* c, int32_t A, int32_t best_of, const int32_
     if (out_ns) out_ns[a] = ns[a * best_of];
   }
   return TTASR_OK;
+  });
 }
 
 int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
                         float patience, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (beam < 1 || beam > 7 || A < 1) return fail(c, TTASR_E_INVALID, "beam must be 1..7 and n_audio >= 1");
   const int R = A * beam;
@@ -1156,10 +1195,12 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     if (out_ns) out_ns[a] = h_ns[a * beam];
   }
   return TTASR_OK;
+  });
 }
 
 int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int32_t hist_stride, int32_t n,
                       const ttasr_gen_opts* o, float* out_rows, int32_t* out_choice) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (n < 1 || n > c->maxB || !rows || !hist || !out_rows) return fail(c, TTASR_E_INVALID, "bad arguments (n <= max_batch)");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1194,23 +1235,29 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   return TTASR_OK;
+  });
 }
 
 int ttasr_phase_ms(ttasr_ctx* c, float out[4]) {
+  return guarded(c, [&]() -> int {
   if (!c || !out) return TTASR_E_INVALID;
   for (int i = 0; i < 4; ++i) out[i] = c->phase_ms[i];
   return TTASR_OK;
+  });
 }
 
 int ttasr_sync(ttasr_ctx* c) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return TTASR_OK;
+  });
 }
 
 int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok, const int32_t* pairs, int32_t n_pairs,
                 float* out_weights, float* out_logprob) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, 1));
   if (!tokens || !pairs || !out_weights) return fail(c, TTASR_E_INVALID, "NULL argument");
   if (clip < 0 || clip >= c->B_enc) return fail(c, TTASR_E_INVALID, "clip %d but the encoder state holds %d", clip, c->B_enc);
@@ -1261,9 +1308,11 @@ int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   return TTASR_OK;
+  });
 }
 
 int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_row, int32_t* out_col, int32_t* out_len) {
+  return guarded(nullptr, [&]() -> int {
   if (!cost || !out_row || !out_col || !out_len || n_rows < 1 || n_cols < 1) return TTASR_E_INVALID;
   const size_t W_ = (size_t)n_cols + 1;
   std::vector<float> acc(((size_t)n_rows + 1) * W_, INFINITY);
@@ -1289,9 +1338,11 @@ int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_ro
   std::reverse(out_col, out_col + n);
   *out_len = n;
   return TTASR_OK;
+  });
 }
 
 int ttasr_set_audio_ctx(ttasr_ctx* c, int32_t n_ctx) {
+  return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (n_ctx == 0) n_ctx = c->cfg.n_audio_ctx;
   if (n_ctx < 4 || n_ctx > c->cfg.n_audio_ctx || (n_ctx & 1))
@@ -1309,10 +1360,12 @@ int ttasr_set_audio_ctx(ttasr_ctx* c, int32_t n_ctx) {
   HIPCHK(c, hipMemsetAsync(c->c1, 0, (size_t)c->maxB * Fmax * c->d * c->esz, c->stream));
   HIPCHK(c, hipMemsetAsync(c->mel_t, 0, (size_t)c->maxB * Fmax * c->M * c->esz, c->stream));
   return TTASR_OK;
+  });
 }
 
 int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters, float* out_ms, double* out_bytes,
                        double* out_flops) {
+  return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (!name || iters < 1 || !out_ms) return fail(c, TTASR_E_INVALID, "bad arguments");
   const std::string k(name);
@@ -1382,6 +1435,7 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
   if (out_bytes) *out_bytes = bytes;
   if (out_flops) *out_flops = flops;
   return TTASR_OK;
+  });
 }
 
 }  // extern "C"
