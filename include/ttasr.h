@@ -12,7 +12,9 @@
  * Conventions: every function returns 0 on success, a negative TTASR_E_* otherwise, and never aborts the
  * process; ttasr_last_error() gives the message.  A context is bound to one GPU and one HIP stream and is
  * NOT re-entrant: one call in flight per context (the reference never issues concurrent transcribe()
- * calls on one model: file_asr.py:175, streaming_asr.py:85-86).  All device memory (weights, paged KV
+ * calls on one model: file_asr.py:175, streaming_asr.py:85-86); a call arriving while another runs on the same context
+ * returns TTASR_E_INVALID at once and leaves the running call untouched.  Different contexts are independent.
+ * No C++ exception crosses this boundary.  All device memory (weights, paged KV
  * pools, workspaces) is owned by the context from ttasr_create to ttasr_destroy.
  * Pointers named *_host are caller-owned host buffers; `pcm` may be a host or device pointer as stated
  * by `pcm_on_device`.

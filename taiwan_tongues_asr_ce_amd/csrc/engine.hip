@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -91,6 +92,7 @@ struct ttasr_ctx {
   int max_new_alloc = 0, max_prompt_alloc = 0;
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
+  std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
   bool no_xsplit = false;   // TTASR_NO_XSPLIT: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // TTASR_NO_PREFILL: feed prompts token by token (A/B testing)
   hipEvent_t ev[8]{};
@@ -633,6 +635,14 @@ int reset_search(ttasr_ctx* c, int B) {
 // No C++ exception may cross the C ABI (std::bad_alloc from a host vector would otherwise terminate the caller's process)
 template <class F>
 static int guarded(ttasr_ctx* c, F&& f) {
+  // a context is not re-entrant (ttasr.h): a call that arrives while another is in flight on the same context is
+  // refused instead of corrupting the search state (its error text is not stored: the other call owns c->err)
+  struct Busy {
+    ttasr_ctx* c; bool own;
+    explicit Busy(ttasr_ctx* c_) : c(c_), own(c_ == nullptr || !c_->busy.test_and_set(std::memory_order_acquire)) {}
+    ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
+  } busy(c);
+  if (!busy.own) return TTASR_E_INVALID;
   try {
     return f();
   } catch (const std::bad_alloc&) {

@@ -291,3 +291,34 @@ def test_short_audio_ctx_matches_oracle_on_the_truncated_window(compute, enc_tol
         with pytest.raises(TtasrError):
             e.set_audio_ctx(bad)
     e.close()
+
+
+def test_concurrent_calls_on_one_context_are_refused(eng_tiny_f32):
+    """ttasr.h: one call in flight per context.  A second thread calling into the same context while a generate runs
+    gets TTASR_E_INVALID instead of corrupting the decode state; the running call is unaffected."""
+    import threading
+    from taiwan_tongues_asr_ce_amd.engine import TtasrError
+    e = eng_tiny_f32
+    st = e.special
+    e.log_mel([synth.noise_clip(0)], want_output=False)
+    e.encode(1)
+    prompt = [st.sot, st.lang_zh, st.transcribe]
+    ref = e.generate([prompt], e.gen_opts(200, True, suppress_eot=True)).tokens
+    out, errors = {}, []
+
+    def long_call():
+        out["tokens"] = e.generate([prompt], e.gen_opts(200, True, suppress_eot=True)).tokens
+
+    t = threading.Thread(target=long_call)
+    t.start()
+    for _ in range(2000):
+        try:
+            e._check(e.lib.ttasr_sync(e.h), "sync")
+        except TtasrError as ex:
+            errors.append(ex)
+        if not t.is_alive():
+            break
+    t.join()
+    assert out["tokens"] == ref                       # the call in flight was not disturbed
+    assert len(errors) > 0                            # at least one intruding call was refused
+    e._check(e.lib.ttasr_sync(e.h), "sync")           # and the context works normally afterwards
