@@ -132,6 +132,15 @@ int ttasr_generate(ttasr_ctx* ctx, int32_t B, const int32_t* prompt_host, const 
 int ttasr_generate_beam(ttasr_ctx* ctx, int32_t n_audio, int32_t beam, const int32_t* prompt_host, int32_t prompt_len,
                         const ttasr_gen_opts* opts, float patience, int32_t* out_tokens_host, int32_t* out_len_host,
                         float* out_sum_logprob_host, float* out_no_speech_host);
+/* The same search with one prompt per clip (prompt_host [n_audio][max_prompt], prompt_len_host[a] tokens valid,
+ * sot_index_host[a] = position of <|startoftranscript|> in clip a's prompt, or NULL for opts->sot_index everywhere): what
+ * a caller needs to run several FILES through one engine pass when each carries its own previous-text prompt
+ * (condition_on_previous_text).  The step loop is position-synchronous: clips with longer prompts are still being forced
+ * while the others already search. */
+int ttasr_generate_beam_ragged(ttasr_ctx* ctx, int32_t n_audio, int32_t beam, const int32_t* prompt_host,
+                               const int32_t* prompt_len_host, const int32_t* sot_index_host, int32_t max_prompt,
+                               const ttasr_gen_opts* opts, float patience, int32_t* out_tokens_host, int32_t* out_len_host,
+                               float* out_sum_logprob_host, float* out_no_speech_host);
 /* Temperature sampling (the fallback ladder of faster-whisper's generate_with_fallback: temperatures 0.2 ... 1.0
  * with best_of hypotheses).  n_audio clips x best_of independently sampled rows that share the clip's cross-KV;
  * tokens are drawn from softmax(processed logits / temperature) with a counter-based generator keyed by

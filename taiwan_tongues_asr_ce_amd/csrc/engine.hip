@@ -1024,20 +1024,32 @@ int ttasr_generate_sample(ttasr_ctx* c, int32_t A, int32_t best_of, const int32_
   });
 }
 
-int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
-                        float patience, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
-  return guarded(c, [&]() -> int {
+// Beam search over A clips x `beam` rows.  Prompts may be ragged: clip a has plens[a] tokens at prompt + a * max_prompt and
+// its <|startoftranscript|> at sots[a]; the step loop is position-synchronous, so at a given position some clips are
+// still being forced through their prompt while others already search.
+static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t max_prompt, const int32_t* plens,
+                            const int32_t* sots, const ttasr_gen_opts* o, float patience, int32_t* out_tokens, int32_t* out_len,
+                            float* out_lp, float* out_ns) {
   if (!c) return TTASR_E_INVALID;
   if (beam < 1 || beam > 7 || A < 1) return fail(c, TTASR_E_INVALID, "beam must be 1..7 and n_audio >= 1");
   const int R = A * beam;
   TRY(check_ready(c, R));
-  if (!prompt || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (!prompt || !plens || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
   if (A > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, A);
-  if (plen < 1 || plen >= c->cfg.n_text_ctx) return fail(c, TTASR_E_INVALID, "prompt_len %d", plen);
-  for (int i = 0; i < A * plen; ++i)
-    if (prompt[i] < 0 || prompt[i] >= c->V) return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
+  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
+  int min_plen = 1 << 30, min_sot = 1 << 30;
+  for (int a = 0; a < A; ++a) {
+    if (plens[a] < 1 || plens[a] > max_prompt || plens[a] >= c->cfg.n_text_ctx) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", a, plens[a]);
+    const int sot = sots ? sots[a] : o->sot_index;
+    if (o->no_speech >= 0 && out_ns && (sot < 0 || sot >= plens[a])) return fail(c, TTASR_E_INVALID, "sot_index[%d]=%d outside the prompt", a, sot);
+    min_plen = std::min(min_plen, (int)plens[a]); min_sot = std::min(min_sot, sot);
+    for (int i = 0; i < plens[a]; ++i)
+      if (prompt[(size_t)a * max_prompt + i] < 0 || prompt[(size_t)a * max_prompt + i] >= c->V)
+        return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
+  }
+  auto sot_of = [&](int a) { return sots ? sots[a] : o->sot_index; };
   RuleParams old_rp = c->rp;
-  TRY(upload_rules(c, o, plen));
+  TRY(upload_rules(c, o, max_prompt));
   if (memcmp(&old_rp, &c->rp, sizeof old_rp) != 0) drop_graphs(c);
   TRY(reset_search(c, R));
   c->st.prompt = nullptr; c->st.prompt_len = nullptr;
@@ -1062,12 +1074,16 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     for (int p = n_pages - 1; p >= 0; --p) if (refcnt[p] == 0) free_pages.push_back(p);
   };
   rebuild_free(-1);
-  for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen];
+  for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(size_t)(r / beam) * max_prompt];
+  std::vector<char> done(A, 0);
+  std::vector<float> ns_final(A, 0.f);
   hipEventRecord(c->ev[5], s);
   // Batched prompt prefill: the beam rows of a clip share one prompt, so its positions are computed ONCE per clip
   // into pages that all `beam` page tables then reference (the copy-on-write below splits the last, partially
   // filled page on the first private write).
-  const int pre = prefill_positions(c, plen, o);
+  // every clip must still be inside its prompt (and before its <|startoftranscript|> when no-speech is wanted)
+  ttasr_gen_opts o_pre = *o; o_pre.sot_index = min_sot;
+  const int pre = prefill_positions(c, min_plen, &o_pre);
   if (pre > 0) {
     const int n_pg = (pre + 15) / 16;
     std::vector<int32_t> ptab((size_t)A * pps, 0);
@@ -1079,13 +1095,13 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
         ptab[(size_t)a * pps + q] = pg;
       }
     HIPCHK(c, hipMemcpyAsync(c->page_table, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * plen * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * max_prompt * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));  // ptab is a stack temporary
-    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1, plen); else run_prefill<float>(c, A, pre, 1, plen);
+    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1, max_prompt); else run_prefill<float>(c, A, pre, 1, max_prompt);
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
     rebuild_free(n_pg - 1);
-    for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pre];
+    for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(size_t)(r / beam) * max_prompt + pre];
   }
   bool stop = false;
   for (int pos = pre; pos < c->cfg.n_text_ctx - 1 && !stop; ++pos) {
@@ -1118,10 +1134,15 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     }
     // 2. one decoder step over the R rows (logits only; the search itself runs on the host)
     TRY(step_graph(c, R, 1));
-    const bool sampling = pos + 1 >= plen;
-    const bool want_ns = o->no_speech >= 0 && pos == o->sot_index && out_ns;
-    if (!sampling && !want_ns) {
-      for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pos + 1];
+    // per clip: still forced through its prompt, searching, or finished
+    auto forced_next = [&](int a) { return prompt[(size_t)a * max_prompt + pos + 1]; };
+    bool any_sampling = false, any_ns = false;
+    for (int a = 0; a < A; ++a) {
+      any_sampling |= !done[a] && pos + 1 >= plens[a];
+      any_ns |= o->no_speech >= 0 && out_ns && pos == sot_of(a);
+    }
+    if (!any_sampling && !any_ns) {
+      for (int r = 0; r < R; ++r) cur_tok[r] = done[r / beam] ? o->eot : forced_next(r / beam);
       continue;
     }
     for (int r = 0; r < R; ++r) {
@@ -1131,18 +1152,24 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     }
     HIPCHK(c, hipMemcpyAsync(c->row_state, h_state.data(), (size_t)4 * R * 4, hipMemcpyHostToDevice, s));
     BeamRowState bs{c->row_state, c->row_state + R, c->row_state + 2 * R, c->row_state + 3 * R, c->mask_dev};
-    launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, want_ns ? c->st.no_speech : nullptr, s);
+    launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, any_ns ? c->st.no_speech : nullptr, s);
     HIPCHK(c, hipMemcpyAsync(h_lp.data(), c->topk_lp, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipMemcpyAsync(h_id.data(), c->topk_id, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
-    if (want_ns) HIPCHK(c, hipMemcpyAsync(h_ns.data(), c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
+    if (any_ns) HIPCHK(c, hipMemcpyAsync(h_ns.data(), c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (!sampling) {
-      for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(r / beam) * plen + pos + 1];
+    for (int a = 0; a < A; ++a)
+      if (o->no_speech >= 0 && out_ns && pos == sot_of(a)) ns_final[a] = h_ns[a * beam];
+    if (!any_sampling) {
+      for (int r = 0; r < R; ++r) cur_tok[r] = done[r / beam] ? o->eot : forced_next(r / beam);
       continue;
     }
     // 3. candidate selection per clip (Whisper BeamSearchDecoder semantics; identical sequences collapse)
     std::vector<std::vector<int>> nseq; std::vector<double> nsum; std::vector<int> src;
     for (int a = 0; a < A; ++a) {
+      if (done[a] || pos + 1 < plens[a]) {  // not searching at this position: hypotheses and page lists carry over unchanged
+        for (int b = 0; b < beam; ++b) { nseq.push_back(seqs[a * beam + b]); nsum.push_back(sums[a * beam + b]); src.push_back(a * beam + b); }
+        continue;
+      }
       std::map<std::vector<int>, std::pair<double, int>> cand;
       for (int b = 0; b < beam; ++b) {
         const int r = a * beam + b;
@@ -1176,10 +1203,17 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     tbl.swap(ntbl);
     rebuild_free(j);
     seqs.swap(nseq); sums.swap(nsum);
-    for (int r = 0; r < R; ++r) cur_tok[r] = seqs[r].back();
-    bool all_full = true;
-    for (int a = 0; a < A; ++a) all_full &= (int)finished[a].size() >= max_cand;
-    if (all_full || (int)seqs[0].size() >= max_new) stop = true;
+    bool all_done = true;
+    for (int a = 0; a < A; ++a) {
+      const bool searching = !done[a] && pos + 1 >= plens[a];
+      if (searching && ((int)finished[a].size() >= max_cand || (int)seqs[a * beam].size() >= max_new)) done[a] = 1;
+      for (int b = 0; b < beam; ++b) {
+        const int r = a * beam + b;
+        cur_tok[r] = done[a] ? o->eot : (searching ? seqs[r].back() : forced_next(a));
+      }
+      all_done &= (bool)done[a];
+    }
+    if (all_done) stop = true;
   }
   hipEventRecord(c->ev[6], s);
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1202,9 +1236,25 @@ int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* pr
     for (int t : *best) if (t != o->eot && n < max_new) out_tokens[(size_t)a * max_new + n++] = t;
     out_len[a] = n;
     if (out_lp) out_lp[a] = (float)best_sum;
-    if (out_ns) out_ns[a] = h_ns[a * beam];
+    if (out_ns) out_ns[a] = ns_final[a];
   }
   return TTASR_OK;
+}
+
+int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
+                        float patience, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  return guarded(c, [&]() -> int {
+    if (A < 1) return fail(c, TTASR_E_INVALID, "n_audio >= 1 required");
+    std::vector<int32_t> plens(A, plen);
+    return beam_search_impl(c, A, beam, prompt, plen, plens.data(), nullptr, o, patience, out_tokens, out_len, out_lp, out_ns);
+  });
+}
+
+int ttasr_generate_beam_ragged(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, const int32_t* prompt_len,
+                               const int32_t* sot_index, int32_t max_prompt, const ttasr_gen_opts* o, float patience,
+                               int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
+  return guarded(c, [&]() -> int {
+    return beam_search_impl(c, A, beam, prompt, max_prompt, prompt_len, sot_index, o, patience, out_tokens, out_len, out_lp, out_ns);
   });
 }
 

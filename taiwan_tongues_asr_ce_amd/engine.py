@@ -170,20 +170,35 @@ class Engine:
                                             lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate")
         return GenResult([toks[b, :lens[b]].tolist() for b in range(B)], lp, ns)
 
-    def generate_beam(self, prompts: Sequence[Sequence[int]], beam: int, opts, patience: float = 1.0) -> GenResult:
-        """Beam search over len(prompts) clips (equal-length prompts); rows = clips * beam <= max_batch."""
+    def generate_beam(self, prompts: Sequence[Sequence[int]], beam: int, opts, patience: float = 1.0,
+                      sot_index: Optional[Sequence[int]] = None) -> GenResult:
+        """Beam search over len(prompts) clips; rows = clips * beam <= max_batch.  Prompts may differ in length (one
+        previous-text prompt per file); sot_index then gives each prompt's <|startoftranscript|> position."""
         A = len(prompts)
-        plen = len(prompts[0])
-        assert all(len(p) == plen for p in prompts), "beam search needs equal-length prompts"
-        pr = np.asarray(prompts, dtype=np.int32).reshape(A, plen)
+        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
         toks = np.zeros((A, opts.max_new_tokens), dtype=np.int32)
         lens = np.zeros(A, dtype=np.int32)
         lp = np.zeros(A, dtype=np.float32)
         ns = np.zeros(A, dtype=np.float32)
-        i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
-        self._check(self.lib.ttasr_generate_beam(self.h, A, beam, pr.ctypes.data_as(i32p), plen, C.byref(opts),
-                                                 C.c_float(patience), toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
-                                                 lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_beam")
+        plen = len(prompts[0])
+        if all(len(p) == plen for p in prompts) and sot_index is None:
+            pr = np.asarray(prompts, dtype=np.int32).reshape(A, plen)
+            self._check(self.lib.ttasr_generate_beam(self.h, A, beam, pr.ctypes.data_as(i32p), plen, C.byref(opts),
+                                                     C.c_float(patience), toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                     lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate_beam")
+        else:
+            max_prompt = max(len(p) for p in prompts)
+            pr = np.zeros((A, max_prompt), dtype=np.int32)
+            pl = np.zeros(A, dtype=np.int32)
+            for a, p in enumerate(prompts):
+                pr[a, :len(p)] = p
+                pl[a] = len(p)
+            so = None if sot_index is None else np.ascontiguousarray(sot_index, dtype=np.int32)
+            self._check(self.lib.ttasr_generate_beam_ragged(
+                self.h, A, beam, pr.ctypes.data_as(i32p), pl.ctypes.data_as(i32p),
+                so.ctypes.data_as(i32p) if so is not None else None, max_prompt, C.byref(opts), C.c_float(patience),
+                toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)),
+                "generate_beam_ragged")
         return GenResult([toks[a, :lens[a]].tolist() for a in range(A)], lp, ns)
 
     def generate_sample(self, prompts: Sequence[Sequence[int]], best_of: int, opts, temperature: float, seed: int = 0

@@ -138,3 +138,45 @@ def test_micro_sampling_matches_oracle(golden_dir, temperature, best_of):
     greedy = e.generate([prompt] * A, e.gen_opts(16, True, suppress=sup, begin_suppress=bsup, check_interval=1))
     assert len(greedy.tokens) == A  # greedy after sampling still works (temperature reset)
     e.close()
+
+
+def test_beam_search_with_one_prompt_per_clip():
+    """Ragged prompts (each clip its own previous-text prefix): every clip's result equals the oracle's beam search
+    run on that clip alone with its own prompt; the no-speech probability is taken at each clip's own SOT position."""
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_F32, PRESETS
+    from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
+    pd = PRESETS["tiny"]
+    dims = R.Dims(**pd.as_dict())
+    e = Engine(pd, COMPUTE_F32, 8)
+    e.load_weights(synth.iter_weights(pd))
+    st = e.special
+    W = R.to_torch(synth.state_dict(pd))
+    clips = [synth.noise_clip(0), synth.tonal_clip(1), synth.burst_clip(2)]
+    e.log_mel(clips, want_output=False)
+    e.encode(3)
+    enc = R.encoder_forward(torch.from_numpy(np.stack([R.log_mel(c, pd.n_mels) for c in clips])), W, dims)
+    rng = np.random.default_rng(21)
+    tail = [st.sot, st.lang_zh, st.transcribe]
+    prompts = []
+    for n_prev in (5, 19, 0):            # 19 previous tokens: prefill of the shortest prompt stops before clip 2's SOT (position 0)
+        prev = ([st.sot_prev] + rng.integers(300, 20000, size=n_prev).tolist()) if n_prev else []
+        prompts.append(prev + tail)
+    sots = [p.index(st.sot) for p in prompts]
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
+    for beam in (2, 1):
+        opts = e.gen_opts(9, True)
+        res = e.generate_beam(prompts, beam, opts, sot_index=sots)
+        for a in range(3):
+            ref = R.beam_decode(enc[a:a + 1], prompts[a], W, dims, rules, beam, 9, no_speech_token=st.no_speech, sot_index=sots[a])
+            assert [t for t in res.tokens[a] if t != st.eot] == [t for t in ref.tokens[0] if t != st.eot], (beam, a)
+            assert abs(float(res.no_speech_prob[a]) - ref.no_speech_prob[0]) < 2e-3 * max(1.0, ref.no_speech_prob[0])
+            assert abs(float(res.sum_logprob[a]) - ref.sum_logprob[0]) < 2e-2
+    # two long prompts: the shared prefill covers the common forced part, the longer prompt continues token by token
+    prompts2 = [[st.sot_prev] + rng.integers(300, 20000, size=n).tolist() + tail for n in (17, 30)]
+    sots2 = [p.index(st.sot) for p in prompts2]
+    res = e.generate_beam(prompts2, 3, e.gen_opts(6, True), sot_index=sots2)
+    for a in range(2):
+        ref = R.beam_decode(enc[a:a + 1], prompts2[a], W, dims, rules, 3, 6, no_speech_token=st.no_speech, sot_index=sots2[a])
+        assert [t for t in res.tokens[a] if t != st.eot] == [t for t in ref.tokens[0] if t != st.eot], a
+    e.close()
