@@ -12,7 +12,9 @@ Mirrors the observable contract of the reference's batch entry point (asr_core.p
 * `asr_comparison_results.json` in the working directory holds `summary` + `detailed_results` with the reference's
   keys (asr_core.py:258-334).
 
-Differences: files are processed in sorted order (the reference iterates a `set`); with several GPUs
+Differences: by default several files advance in lock step through one engine pass per window round
+(`WhisperModel.transcribe_many`: same per-file algorithm and outputs as one by one, batch throughput; `--group-files 1`
+restores strictly sequential processing); files are processed in sorted order (the reference iterates a `set`); with several GPUs
 (`torchrun --nproc-per-node N -m taiwan_tongues_asr_ce_amd.batch_cli folder`) files are sharded by rank — never by
 window, windows of one file are sequentially dependent — and rank 0 merges the per-rank results; only RIFF/WAV is
 decodable without librosa/PyAV, other containers are reported as per-file errors.
@@ -55,12 +57,15 @@ def _load_audio(path: str):
     return decode_audio(path)
 
 
-def transcribe_file(model, audio_file: str, load_audio: Callable = _load_audio, log: Callable = print) -> Dict:
-    """One unit of work → one entry of `detailed_results`."""
+def transcribe_file(model, audio_file: str, load_audio: Callable = _load_audio, log: Callable = print, segments=None) -> Dict:
+    """One unit of work → one entry of `detailed_results`.  `segments`: already transcribed (group mode), else runs it."""
     name = os.path.basename(audio_file)
     out_path = os.path.splitext(audio_file)[0] + "_asr.txt"
     try:
-        segments, _info = model.transcribe(load_audio(audio_file), **TRANSCRIBE_KWARGS)
+        if isinstance(segments, Exception):
+            raise segments
+        if segments is None:
+            segments, _info = model.transcribe(load_audio(audio_file), **TRANSCRIBE_KWARGS)
         text = "".join(seg.text for seg in segments)            # consumes the lazy generator: this is where it runs
         processed = scoring.normalise_transcript(text)
         with open(out_path, "w", encoding="utf-8") as f:
@@ -110,17 +115,43 @@ def summarise(results: List[Dict]) -> Dict:
 
 
 def process_audio_folder(folder_path: str, model=None, model_path: str = "models", device: str = "cuda",
-                         device_index: int = 0, compute_type: str = "float16", output_json: Optional[str] = None, rank: int = 0,
-                         world: int = 1, load_audio: Callable = _load_audio, log: Callable = print) -> Optional[Dict]:
+                         device_index: int = 0, compute_type: str = "float16", max_batch: int = 30, output_json: Optional[str] = None, rank: int = 0,
+                         world: int = 1, load_audio: Callable = _load_audio, log: Callable = print,
+                         group_files: int = 0) -> Optional[Dict]:
     files = list_audio_files(folder_path)
     if not files:
         log(f"no audio files in {folder_path}")
         return None
     if model is None:
         from .model import WhisperModel
-        model = WhisperModel(model_path, device=device, device_index=device_index, compute_type=compute_type)
+        model = WhisperModel(model_path, device=device, device_index=device_index, compute_type=compute_type,
+                             max_batch=max_batch)
     mine = files[rank::world]                                   # shard by file
-    results = [transcribe_file(model, f, load_audio, log) for f in mine]
+    results = []
+    many = getattr(model, "transcribe_many", None)
+    group = group_files if group_files > 0 else max(1, getattr(model, "max_batch", 1) // TRANSCRIBE_KWARGS["beam_size"])
+    if many is None or group < 2 or getattr(model, "vad_speech_prob_fn", None) is not None:
+        results = [transcribe_file(model, f, load_audio, log) for f in mine]
+    else:
+        # MI355X-first: `group` files advance in lock step through one engine pass per window round; every file keeps the
+        # sequential algorithm (own seek / prompt / fallback), so the outputs equal the one-by-one run
+        kw = {k: v for k, v in TRANSCRIBE_KWARGS.items() if k != "vad_filter"}   # no VAD source configured: all-speech
+        for g in range(0, len(mine), group):
+            part = mine[g:g + group]
+            audios, loaded = [], []
+            for f in part:
+                try:
+                    audios.append(load_audio(f))
+                    loaded.append(None)
+                except Exception as e:
+                    loaded.append(e)
+            try:
+                done = iter(many(audios, **kw)) if audios else iter(())
+                segs = [err if err is not None else next(done)[0] for err in loaded]
+            except Exception as e:  # engine-level failure of the group: fall back to one by one
+                log(f"group transcription failed ({e}); retrying file by file")
+                segs = [None] * len(part)
+            results.extend(transcribe_file(model, f, load_audio, log, segments=sg) for f, sg in zip(part, segs))
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world
@@ -143,6 +174,9 @@ def main(argv=None) -> int:
     ap.add_argument("--output", default="transcription_results.txt", help="accepted for compatibility; unused")
     ap.add_argument("--model", default="models", help="HF-format Whisper directory, or synthetic:<preset>")
     ap.add_argument("--compute-type", default="float16")
+    ap.add_argument("--group-files", type=int, default=0,
+                    help="files transcribed in lock step per engine pass (0 = as many as fit: max_batch // beam; 1 = one by one)")
+    ap.add_argument("--max-batch", type=int, default=30, help="decode rows of the engine (files in a group x beam 5)")
     args = ap.parse_args(argv)
     if not os.path.exists(args.folder):
         print(f"folder does not exist: {args.folder}")
@@ -152,7 +186,8 @@ def main(argv=None) -> int:
         from .dist import init_process_group
         rank, world, local = init_process_group()
     process_audio_folder(args.folder, model_path=args.model, device="cuda", device_index=local,
-                         compute_type=args.compute_type, rank=rank, world=world)
+                         compute_type=args.compute_type, rank=rank, world=world, group_files=args.group_files,
+                         max_batch=args.max_batch)
     return 0
 
 

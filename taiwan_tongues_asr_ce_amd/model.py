@@ -310,94 +310,209 @@ class WhisperModel:
             segments = vad.restore_speech_timestamps(segments, chunks)
         return segments, info
 
+    # -- pieces of faster-whisper's generate_segments / generate_with_fallback, shared by the single-file loop and by
+    #    transcribe_many (several files in lock step through one engine pass) -------------------------------------
+    def _score(self, res, row: int):
+        """(tokens, avg_logprob, no_speech_prob, compression_ratio) of one decoded row."""
+        st = self.special
+        toks = res.tokens[row]
+        # faster-whisper: avg_logprob = cum_logprob / (seq_len + 1), seq_len without <|endoftext|> (whose
+        # log-probability is part of the sum): the same divisor whether or not this path returns the EOT
+        n_tok = len([t for t in toks if t != st.eot]) + 1
+        avg_lp = float(res.sum_logprob[row]) / n_tok
+        raw = self.tokenizer.decode([t for t in toks if t < st.eot]).encode("utf-8")
+        cr = (len(raw) / max(1, len(zlib.compress(raw)))) if raw else 0.0
+        return toks, avg_lp, float(res.no_speech_prob[row]), cr
+
+    @staticmethod
+    def _needs_fallback(avg_lp, ns, cr, p) -> bool:
+        if p["no_speech_threshold"] is not None and ns > p["no_speech_threshold"]:
+            return False  # silence: do not retry
+        return (p["compression_ratio_threshold"] is not None and cr > p["compression_ratio_threshold"]) or \
+               (p["log_prob_threshold"] is not None and avg_lp < p["log_prob_threshold"])
+
+    def _decode_with_fallback(self, prompt, opts, seek: int, p, first=None):
+        """generate_with_fallback for the clip resident at index 0: temperature 0 = beam/greedy (or `first`, an already
+        scored temperature-0 attempt), then sampled retries (best_of hypotheses) while the result is too repetitive
+        (zlib compression ratio) or too unlikely (avg log-prob).  -> (temperature, tokens, avg_lp, no_speech, ratio)"""
+        eng = self.engine
+        attempts = []
+        for temp in p["temperatures"]:
+            if temp <= 0.0 and first is not None:
+                toks, avg_lp, ns, cr = first
+            else:
+                if temp <= 0.0:
+                    res = eng.generate_beam([prompt], p["beam_size"], opts, p["patience"]) if p["beam_size"] > 1 \
+                        else eng.generate([prompt], opts)
+                else:
+                    rows = max(1, min(p["best_of"], self.max_batch))
+                    res = eng.generate_sample([prompt], rows, opts, temp, seed=(seek * 1000003 + int(temp * 1000)) & 0x7FFFFFFF)
+                toks, avg_lp, ns, cr = self._score(res, 0)
+            attempts.append((temp, toks, avg_lp, ns, cr))
+            if not self._needs_fallback(avg_lp, ns, cr, p):
+                return attempts[-1]
+        # every temperature failed: keep the most likely attempt among the non-repetitive ones
+        thr = p["compression_ratio_threshold"]
+        ok = [a for a in attempts if thr is None or a[4] <= thr]
+        return max(ok or attempts, key=lambda a: a[2])
+
+    def _window_opts(self, prompt_len: int, sot_index: int, p):
+        st = self.special
+        budget = min(p["max_new"], self.dims.n_text_ctx - prompt_len)
+        return self.engine.gen_opts(budget, timestamps=not p["without_timestamps"], sot_index=sot_index,
+                                    begin_suppress=[220, st.eot] if p["suppress_blank"] else [],
+                                    max_initial_timestamp_index=int(round(p["max_initial_timestamp"] / 0.02)), check_interval=4)
+
+    def _finish_window(self, fs: dict, clip_index: int, attempt, win_frames: int, p) -> List[Segment]:
+        """Turns one window's chosen attempt into segments and advances the file state `fs` (seek, previous tokens,
+        prompt reset, segment counter).  The window's encoder state must still be resident at `clip_index` when word
+        timestamps are wanted."""
+        eng, st = self.engine, self.special
+        temp_used, toks, avg_lp, ns, cr = attempt
+        seek = fs["seek"]
+        time_offset = seek * HOP / SAMPLE_RATE
+        if p["no_speech_threshold"] is not None and ns > p["no_speech_threshold"] and \
+                (p["log_prob_threshold"] is None or avg_lp < p["log_prob_threshold"]):
+            fs["seek"] += win_frames  # silent window: skip it entirely
+            return []
+        segs, advance = self._split_segments(toks, seek, win_frames, time_offset, p["without_timestamps"])
+        limit = time_offset + win_frames * HOP / SAMPLE_RATE  # never report times past the audio that exists
+        kept = []
+        for (s0, s1, stoks) in segs:
+            text = self.tokenizer.decode([t for t in stoks if t < st.eot])
+            s0, s1 = min(s0, limit), min(s1, limit)
+            if s0 >= s1 or not text.strip():
+                continue
+            kept.append(dict(start=s0, end=s1, tokens=list(stoks), text=text, eot=st.eot, words=None))
+        if p["word_timestamps"] and kept:
+            # faster-whisper add_word_timestamps: one alignment pass over the window's text tokens (the encoder
+            # state of this window is still resident), then words are dealt to the segments
+            text_tokens = [t for seg in kept for t in seg["tokens"] if t < st.eot]
+            task_tok = st.translate if p["task"] == "translate" else st.transcribe
+            found = alignment.find_alignment(eng, self.tokenizer, st, clip_index, text_tokens, win_frames, self.alignment_heads,
+                                             p["language"], p["lang_tok"], task_tok)
+            alignment.add_word_timestamps(kept, found, time_offset)
+            for seg in kept:
+                seg["start"], seg["end"] = min(seg["start"], limit), min(seg["end"], limit)
+        out = []
+        for seg in kept:
+            out.append(Segment(fs["idx"], seek, round(seg["start"], 3), round(seg["end"], 3), seg["text"], seg["tokens"],
+                               temp_used, avg_lp, cr, ns, seg["words"]))
+            fs["idx"] += 1
+            # faster-whisper's all_tokens: the tokens of every YIELDED segment, timestamp tokens included (the
+            # previous-text prompt carries them), <|endoftext|> and the undecided tail after the last pair excluded
+            fs["prev"].extend(t for t in seg["tokens"] if t != st.eot)
+        if not p["condition"] or temp_used > 0.5:  # faster-whisper: prompt_reset_on_temperature = 0.5
+            fs["prompt_reset"] = len(fs["prev"])  # prompt_reset_since: nothing carries over
+        fs["seek"] += min(advance, win_frames) if advance > 0 else win_frames
+        return out
+
+    def _new_file_state(self, audio: np.ndarray, initial_prompt: Optional[str]) -> dict:
+        prev: List[int] = []
+        if initial_prompt:
+            prev.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
+        return dict(audio=audio, n_total=int(np.ceil(len(audio) / HOP)) if len(audio) else 0, prev=prev, prompt_reset=0,
+                    seek=0, idx=0)
+
+    def _params(self, language, task, condition, without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
+                max_initial_timestamp, suppress_blank, beam_size, patience, temperatures, best_of,
+                compression_ratio_threshold, word_timestamps) -> dict:
+        return dict(language=language, lang_tok=self._lang_token(language), task=task, condition=condition,
+                    without_timestamps=without_timestamps, max_new=max_new_tokens or (self.dims.n_text_ctx // 2),
+                    no_speech_threshold=no_speech_threshold, log_prob_threshold=log_prob_threshold,
+                    max_initial_timestamp=max_initial_timestamp, suppress_blank=suppress_blank, beam_size=beam_size,
+                    patience=patience, temperatures=tuple(temperatures), best_of=best_of,
+                    compression_ratio_threshold=compression_ratio_threshold, word_timestamps=word_timestamps)
+
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
                            no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,
                            patience=1.0, temperatures=(0.0,), best_of=5, compression_ratio_threshold=2.4,
                            word_timestamps=False) -> Iterator[Segment]:
-        eng, st = self.engine, self.special
-        lang_tok = self._lang_token(language)
-        n_total = int(np.ceil(len(audio) / HOP)) if len(audio) else 0
-        prev: List[int] = []
-        if initial_prompt:
-            prev.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
-        prompt_reset = 0
-        seek, idx = 0, 0
-        n_win = self.dims.n_frames
-        max_new = max_new_tokens or (self.dims.n_text_ctx // 2)
-        while seek < n_total:
-            chunk = audio[seek * HOP: seek * HOP + self.n_window]
-            win_frames = min(n_win, n_total - seek)
+        eng = self.engine
+        p = self._params(language, task, condition, without_timestamps, max_new_tokens, no_speech_threshold,
+                         log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size, patience, temperatures, best_of,
+                         compression_ratio_threshold, word_timestamps)
+        fs = self._new_file_state(audio, initial_prompt)
+        while fs["seek"] < fs["n_total"]:
+            seek = fs["seek"]
+            win_frames = min(self.dims.n_frames, fs["n_total"] - seek)
             eng.set_audio_ctx(0)
-            eng.log_mel([chunk], want_output=False)
+            eng.log_mel([audio[seek * HOP: seek * HOP + self.n_window]], want_output=False)
             eng.encode(1)
-            prompt, sot_index = self._prompt(lang_tok, task, without_timestamps, prev[prompt_reset:])
-            budget = min(max_new, self.dims.n_text_ctx - len(prompt))
-            opts = eng.gen_opts(budget, timestamps=not without_timestamps, sot_index=sot_index,
-                                begin_suppress=[220, st.eot] if suppress_blank else [],
-                                max_initial_timestamp_index=int(round(max_initial_timestamp / 0.02)), check_interval=4)
-            # generate_with_fallback of faster-whisper: temperature 0 = beam/greedy, then sampled retries (best_of
-            # hypotheses) while the result is too repetitive (zlib compression ratio) or too unlikely (avg log-prob)
-            attempts = []
-            for temp in temperatures:
-                if temp <= 0.0:
-                    res = eng.generate_beam([prompt], beam_size, opts, patience) if beam_size > 1 else eng.generate([prompt], opts)
-                else:
-                    rows = max(1, min(best_of, self.max_batch))
-                    res = eng.generate_sample([prompt], rows, opts, temp, seed=(seek * 1000003 + int(temp * 1000)) & 0x7FFFFFFF)
-                toks = res.tokens[0]
-                # faster-whisper: avg_logprob = cum_logprob / (seq_len + 1), seq_len without <|endoftext|> (whose
-                # log-probability is part of the sum): the same divisor whether or not this path returns the EOT
-                n_tok = len([t for t in toks if t != st.eot]) + 1
-                avg_lp = float(res.sum_logprob[0]) / n_tok
-                ns = float(res.no_speech_prob[0])
-                text_all = self.tokenizer.decode([t for t in toks if t < st.eot])
-                raw = text_all.encode("utf-8")
-                cr = (len(raw) / max(1, len(zlib.compress(raw)))) if raw else 0.0
-                attempts.append((temp, toks, avg_lp, ns, cr))
-                needs_fallback = (compression_ratio_threshold is not None and cr > compression_ratio_threshold) or \
-                                 (log_prob_threshold is not None and avg_lp < log_prob_threshold)
-                if no_speech_threshold is not None and ns > no_speech_threshold:
-                    needs_fallback = False  # silence: do not retry
-                if not needs_fallback:
-                    break
-            else:  # every temperature failed: keep the most likely attempt among the non-repetitive ones
-                ok = [a for a in attempts if compression_ratio_threshold is None or a[4] <= compression_ratio_threshold]
-                attempts.append(max(ok or attempts, key=lambda a: a[2]))
-            temp_used, toks, avg_lp, ns, cr = attempts[-1]
-            time_offset = seek * HOP / SAMPLE_RATE
-            if no_speech_threshold is not None and ns > no_speech_threshold and \
-                    (log_prob_threshold is None or avg_lp < log_prob_threshold):
-                seek += win_frames  # silent window: skip it entirely
-                continue
-            segs, advance = self._split_segments(toks, seek, win_frames, time_offset, without_timestamps)
-            limit = time_offset + win_frames * HOP / SAMPLE_RATE  # never report times past the audio that exists
-            kept = []
-            for (s0, s1, stoks) in segs:
-                text = self.tokenizer.decode([t for t in stoks if t < st.eot])
-                s0, s1 = min(s0, limit), min(s1, limit)
-                if s0 >= s1 or not text.strip():
-                    continue
-                kept.append(dict(start=s0, end=s1, tokens=list(stoks), text=text, eot=st.eot, words=None))
-            if word_timestamps and kept:
-                # faster-whisper add_word_timestamps: one alignment pass over the window's text tokens (the encoder
-                # state of this window is still resident), then words are dealt to the segments
-                text_tokens = [t for seg in kept for t in seg["tokens"] if t < st.eot]
-                task_tok = st.translate if task == "translate" else st.transcribe
-                found = alignment.find_alignment(eng, self.tokenizer, st, 0, text_tokens, win_frames, self.alignment_heads,
-                                                 language, lang_tok, task_tok)
-                alignment.add_word_timestamps(kept, found, time_offset)
-                for seg in kept:
-                    seg["start"], seg["end"] = min(seg["start"], limit), min(seg["end"], limit)
-            for seg in kept:
-                yield Segment(idx, seek, round(seg["start"], 3), round(seg["end"], 3), seg["text"], seg["tokens"], temp_used,
-                              avg_lp, cr, ns, seg["words"])
-                idx += 1
-                # faster-whisper's all_tokens: the tokens of every YIELDED segment, timestamp tokens included (the
-                # previous-text prompt carries them), <|endoftext|> and the undecided tail after the last pair excluded
-                prev.extend(t for t in seg["tokens"] if t != st.eot)
-            if not condition or temp_used > 0.5:  # faster-whisper: prompt_reset_on_temperature = 0.5
-                prompt_reset = len(prev)  # prompt_reset_since: nothing carries over
-            seek += min(advance, win_frames) if advance > 0 else win_frames
+            prompt, sot_index = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:])
+            attempt = self._decode_with_fallback(prompt, self._window_opts(len(prompt), sot_index, p), seek, p)
+            yield from self._finish_window(fs, 0, attempt, win_frames, p)
+
+    def transcribe_many(self, audios: Sequence[Union[str, np.ndarray]], language: str = "zh", task: str = "transcribe",
+                        beam_size: int = 5, word_timestamps: bool = False, condition_on_previous_text: bool = True,
+                        initial_prompt: Optional[str] = None, without_timestamps: bool = False,
+                        max_new_tokens: Optional[int] = None, no_speech_threshold: Optional[float] = 0.6,
+                        log_prob_threshold: Optional[float] = -1.0, max_initial_timestamp: float = 1.0,
+                        suppress_blank: bool = True, temperature: Union[float, Sequence[float]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+                        best_of: int = 5, compression_ratio_threshold: Optional[float] = 2.4, patience: float = 1.0
+                        ) -> List[Tuple[List[Segment], TranscriptionInfo]]:
+        """Several FILES in lock step: every round takes the next 30-s window of each unfinished file and runs them as
+        ONE engine pass (log-mel, encoder, beam search with one previous-text prompt per file), so a folder is
+        transcribed at batch throughput while each file keeps exactly the sequential algorithm of `transcribe` — its
+        own seek, prompt, thresholds.  A window that fails the temperature-0 thresholds is re-decoded alone through the
+        same fallback ladder.  Files are sharded by file across GPUs by the caller (batch_cli), never by window."""
+        eng = self.engine
+        beam = max(1, min(beam_size, 7, self.max_batch))
+        per_pass = max(1, self.max_batch // beam)
+        temps = tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),)
+        p = self._params(language, task, condition_on_previous_text, without_timestamps, max_new_tokens, no_speech_threshold,
+                         log_prob_threshold, max_initial_timestamp, suppress_blank, beam, patience, temps, best_of,
+                         compression_ratio_threshold, bool(word_timestamps))
+        files = []
+        for a in audios:
+            a = decode_audio(a) if isinstance(a, str) else np.asarray(a)
+            if a.ndim != 1:
+                raise ValueError(f"audio must be mono float32 [n] @16 kHz, got shape {a.shape}")
+            fs = self._new_file_state(np.ascontiguousarray(a, dtype=np.float32), initial_prompt)
+            fs["segments"] = []
+            files.append(fs)
+        while True:
+            active = [fs for fs in files if fs["seek"] < fs["n_total"]]
+            if not active:
+                break
+            for g in range(0, len(active), per_pass):
+                group = active[g:g + per_pass]
+                chunks = [fs["audio"][fs["seek"] * HOP: fs["seek"] * HOP + self.n_window] for fs in group]
+                eng.set_audio_ctx(0)
+                eng.log_mel(chunks, want_output=False)
+                eng.encode(len(group))
+                prompts, sots = [], []
+                for fs in group:
+                    pr, si = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:])
+                    prompts.append(pr)
+                    sots.append(si)
+                # one budget for the pass: the shortest prompt's; the 448-token context cuts longer prompts' rows short
+                opts = self._window_opts(min(len(pr) for pr in prompts), 0, p)
+                res = eng.generate_beam(prompts, beam, opts, patience, sot_index=sots)
+                first = [self._score(res, i) for i in range(len(group))]
+                redo = []
+                for i, fs in enumerate(group):
+                    toks, avg_lp, ns, cr = first[i]
+                    win_frames = min(self.dims.n_frames, fs["n_total"] - fs["seek"])
+                    if temps[0] <= 0.0 and self._needs_fallback(avg_lp, ns, cr, p) and len(temps) > 1:
+                        redo.append((fs, prompts[i], sots[i], first[i], win_frames, chunks[i]))
+                    else:
+                        fs["segments"].extend(self._finish_window(fs, i, (temps[0], toks, avg_lp, ns, cr), win_frames, p))
+                for fs, pr, si, fst, win_frames, chunk in redo:   # rare: this window alone, through the whole ladder
+                    eng.log_mel([chunk], want_output=False)
+                    eng.encode(1)
+                    attempt = self._decode_with_fallback(pr, self._window_opts(len(pr), si, p), fs["seek"], p, first=fst)
+                    fs["segments"].extend(self._finish_window(fs, 0, attempt, win_frames, p))
+        out = []
+        for fs in files:
+            dur = len(fs["audio"]) / SAMPLE_RATE
+            info = TranscriptionInfo(language=language, language_probability=1.0, duration=dur, duration_after_vad=dur,
+                                     all_language_probs=None,
+                                     transcription_options=dict(beam_size=beam, task=task, without_timestamps=without_timestamps,
+                                                                condition_on_previous_text=condition_on_previous_text,
+                                                                initial_prompt=initial_prompt))
+            out.append((fs["segments"], info))
+        return out
 
     # ------------------------------------------------------------------------------------------
     def transcribe_batch(self, clips: Sequence[np.ndarray], language: str = "zh", task: str = "transcribe",

@@ -77,3 +77,40 @@ def test_process_audio_folder_contract(tmp_path, monkeypatch):
 def test_empty_folder_and_missing_folder(tmp_path, capsys):
     assert batch_cli.process_audio_folder(str(tmp_path), model=_Model([]), log=lambda *_: None) is None
     assert batch_cli.main([str(tmp_path / "nope")]) == 1
+
+
+class _GroupModel(_Model):
+    """Double with the group entry point: records how files were grouped."""
+    max_batch = 10      # // beam 5 -> 2 files per engine pass
+
+    def __init__(self, texts, fail_groups=()):
+        super().__init__(texts)
+        self.groups, self.fail_groups = [], set(fail_groups)
+
+    def transcribe_many(self, audios, *, language, word_timestamps, beam_size, condition_on_previous_text, initial_prompt):
+        self.groups.append([len(a) for a in audios])
+        if len(self.groups) - 1 in self.fail_groups:
+            raise RuntimeError("engine fault")
+        out = []
+        for a in audios:
+            out.append(([_Seg(f"長{len(a)}")], object()))
+        return out
+
+
+def test_group_mode_batches_files_and_degrades_per_file(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    folder = tmp_path / "audio"; folder.mkdir()
+    for i, n in enumerate((100, 200, 300, 400, 500)):
+        _wav(folder / f"f{i}.wav", n)
+    (folder / "f1.wav").write_bytes(b"not a wav")                       # unreadable file inside a group
+    model = _GroupModel([["fallback-a"], ["fallback-b"]], fail_groups={2})
+    final = batch_cli.process_audio_folder(str(folder), model=model, log=lambda *_: None)
+    assert model.groups == [[100], [300, 400], [500]]                   # f0 (+ broken f1), f2+f3, f4 (group 2 fails)
+    r = final["detailed_results"]
+    assert [x["asr_result"] for x in r] == ["長100", None, "長300", "長400", "fallback-a"]
+    assert "error" in r[1] and (folder / "f1_asr.txt").read_text(encoding="utf-8").startswith("檔案名稱: f1.wav")
+    assert len(model.calls) == 1 and model.calls[0]["n"] == 500         # only the failed group was retried one by one
+    # --group-files 1 restores strictly sequential processing
+    model2 = _GroupModel([["x"]] * 5)
+    batch_cli.process_audio_folder(str(folder), model=model2, log=lambda *_: None, group_files=1)
+    assert model2.groups == [] and len(model2.calls) == 4               # the unreadable file never reaches the model

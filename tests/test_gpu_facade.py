@@ -230,3 +230,27 @@ def test_hf_directory_with_generation_config_alignment_heads(tmp_path):
     w, lp = eng.align(0, toks, m.alignment_heads)
     rw, rlp = R.alignment_weights(torch.from_numpy(enc_ref), toks, W, rd, m.alignment_heads, return_logprobs=True)
     assert np.abs(w - rw.numpy()).max() < 2e-5 and np.abs(lp - rlp.numpy()).max() < 2e-3
+
+
+def test_transcribe_many_equals_file_by_file(model):
+    """Several files in lock step through one engine pass (ragged-prompt beam search) == the same files transcribed
+    one after the other: same segments, tokens and times; also through the fallback ladder and with word timestamps."""
+    files = [np.concatenate([synth.tonal_clip(0), synth.noise_clip(1)[: 10 * 16000]]),      # 40 s: two windows
+             np.concatenate([synth.noise_clip(2), synth.tonal_clip(3), synth.burst_clip(4)[: 15 * 16000]]),   # 75 s
+             synth.tonal_clip(5)[: 20 * 16000]]                                               # 20 s: one short window
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(beam_size=2, temperature=0.0, log_prob_threshold=None, max_new_tokens=20),
+                   dict(beam_size=1, temperature=0.0, log_prob_threshold=None, max_new_tokens=16, word_timestamps=True),
+                   dict(beam_size=2, temperature=(0.0, 0.4), best_of=2, max_new_tokens=12)):        # default thresholds: ladder
+            many = model.transcribe_many(files, language="zh", **kw)
+            assert len(many) == 3
+            for audio, (segs, info) in zip(files, many):
+                ref, ref_info = model.transcribe(audio, language="zh", **kw)
+                ref = list(ref)
+                assert abs(info.duration - ref_info.duration) < 1e-9
+                assert [s.tokens for s in segs] == [s.tokens for s in ref], kw
+                assert [(s.seek, s.start, s.end, s.temperature) for s in segs] == [(s.seek, s.start, s.end, s.temperature) for s in ref]
+                if kw.get("word_timestamps"):
+                    assert [[(w.word, w.start, w.end) for w in s.words] for s in segs] == \
+                           [[(w.word, w.start, w.end) for w in s.words] for s in ref]
