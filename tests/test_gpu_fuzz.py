@@ -63,8 +63,11 @@ def test_random_configuration_matches_oracle(ctx, seed):
     tail = [st.sot, st.lang_zh, st.transcribe] + ([] if timestamps else [st.no_timestamps])
     mode = ["greedy", "greedy", "beam", "sample"][int(rng.integers(0, 4))]
     room = pd.n_text_ctx - len(tail) - 2
+    max_initial = [None, 0, 7, 50][int(rng.integers(0, 4))]
+    suppress_eot = bool(rng.integers(0, 4) == 0)
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=suppress,
-                    begin_suppress=begin_suppress, timestamps=timestamps)
+                    begin_suppress=begin_suppress, timestamps=timestamps, max_initial_timestamp_index=max_initial,
+                    suppress_eot=suppress_eot)
     if mode == "greedy":
         # ragged prompts: each row its own previous-text prefix (0..12 tokens) -> exercises prefill + forced steps
         prompts = []
@@ -74,7 +77,8 @@ def test_random_configuration_matches_oracle(ctx, seed):
             prompts.append(prev + tail)
         max_new = int(rng.integers(1, pd.n_text_ctx - max(len(p) for p in prompts)))
         opts = e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=begin_suppress, no_speech=False,
-                          check_interval=int(rng.integers(1, 5)))
+                          check_interval=int(rng.integers(1, 5)), max_initial_timestamp_index=max_initial,
+                          suppress_eot=suppress_eot)
         res = e.generate(prompts, opts)
         for b in range(B):
             ref = R.greedy_decode(enc_ref[b:b + 1], prompts[b], W, dims, rules, max_new)
@@ -86,7 +90,8 @@ def test_random_configuration_matches_oracle(ctx, seed):
         prompt = prev + tail
         sot_index = prompt.index(st.sot)
         max_new = int(rng.integers(2, pd.n_text_ctx - len(prompt)))
-        opts = e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=begin_suppress, sot_index=sot_index)
+        opts = e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=begin_suppress, sot_index=sot_index,
+                          max_initial_timestamp_index=max_initial, suppress_eot=suppress_eot)
         width = int(rng.integers(2, 5))
         A = max(1, min(B, 8 // width))
         if mode == "beam":
