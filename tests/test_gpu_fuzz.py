@@ -158,3 +158,37 @@ def test_random_configuration_bf16_within_tolerance(ctx_bf16, seed):
             assert s[t] > -np.inf and float(s.max() - s[t]) < 0.15, (seed, b, i)
             logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
     e.set_audio_ctx(0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_ragged_beam_matches_per_clip_oracle(ctx, seed):
+    """Beam search with one random prompt per clip (different previous-text lengths, so clips leave their prompts at
+    different positions) == the oracle's beam search on each clip alone."""
+    e, pd, dims, W = ctx
+    st = e.special
+    rng = np.random.default_rng(9000 + seed)
+    width = int(rng.integers(1, 4))
+    A = int(rng.integers(2, 8 // width + 1))
+    e.set_audio_ctx(0)
+    clips = _clips(rng, A, pd.n_audio_ctx)
+    want_mel = np.stack([R.log_mel(c, pd.n_mels, n_samples=pd.n_audio_ctx * 320) for c in clips])
+    e.log_mel(clips, want_output=False)
+    e.encode(A)
+    enc_ref = R.encoder_forward(torch.from_numpy(want_mel), W, dims)
+    timestamps = bool(rng.integers(0, 2))
+    tail = [st.sot, st.lang_zh, st.transcribe] + ([] if timestamps else [st.no_timestamps])
+    prompts = []
+    for _ in range(A):
+        n_prev = int(rng.integers(0, 14))
+        prev = ([st.sot_prev] + rng.integers(0, st.eot, size=n_prev).tolist()) if n_prev else []
+        prompts.append(prev + tail)
+    sots = [p.index(st.sot) for p in prompts]
+    max_new = int(rng.integers(2, pd.n_text_ctx - max(len(p) for p in prompts)))
+    suppress = sorted({st.sot, st.sot_prev, st.no_speech} | set(rng.integers(0, st.eot, size=5).tolist()))
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin, suppress=suppress,
+                    begin_suppress=[st.eot], timestamps=timestamps)
+    res = e.generate_beam(prompts, width, e.gen_opts(max_new, timestamps, suppress=suppress, begin_suppress=[st.eot]), sot_index=sots)
+    for a in range(A):
+        ref = R.beam_decode(enc_ref[a:a + 1], prompts[a], W, dims, rules, width, max_new, no_speech_token=st.no_speech, sot_index=sots[a])
+        assert [t for t in res.tokens[a] if t != st.eot] == [t for t in ref.tokens[0] if t != st.eot], (seed, a)
+        assert abs(float(res.no_speech_prob[a]) - ref.no_speech_prob[0]) < 2e-3 * max(1.0, ref.no_speech_prob[0]) + 1e-6
