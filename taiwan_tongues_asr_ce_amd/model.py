@@ -255,6 +255,21 @@ class WhisperModel:
                    temperature: Union[float, Sequence[float]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0), best_of: int = 5,
                    compression_ratio_threshold: Optional[float] = 2.4, **kwargs
                    ) -> Tuple[Iterator[Segment], TranscriptionInfo]:
+        # faster-whisper options this build does not implement are never silently ignored when they differ from
+        # their defaults (the reference call sites pass none of them)
+        neutral = {"patience": None, "vad_parameters": None, "vad_speech_prob_fn": None, "length_penalty": 1, "repetition_penalty": 1,
+                   "no_repeat_ngram_size": 0, "prefix": None, "hotwords": None, "clip_timestamps": "0",
+                   "hallucination_silence_threshold": None, "prompt_reset_on_temperature": 0.5, "suppress_tokens": [-1],
+                   "prepend_punctuations": alignment.PREPEND_PUNCTUATIONS, "append_punctuations": alignment.APPEND_PUNCTUATIONS,
+                   "multilingual": False, "language_detection_threshold": 0.5, "language_detection_segments": 1,
+                   "chunk_length": None, "log_progress": False}
+        for k, v in kwargs.items():
+            if k in ("patience", "vad_parameters", "vad_speech_prob_fn"):
+                continue
+            if k not in neutral:
+                raise TypeError(f"transcribe() got an unexpected keyword argument {k!r}")
+            if v is not None and v != neutral[k]:
+                warnings.warn(f"transcribe(): option {k}={v!r} is not implemented in this build and is ignored", stacklevel=2)
         if isinstance(audio, str):
             audio = decode_audio(audio)
         audio = np.asarray(audio)

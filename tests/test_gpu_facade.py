@@ -254,3 +254,17 @@ def test_transcribe_many_equals_file_by_file(model):
                 if kw.get("word_timestamps"):
                     assert [[(w.word, w.start, w.end) for w in s.words] for s in segs] == \
                            [[(w.word, w.start, w.end) for w in s.words] for s in ref]
+
+
+def test_unsupported_options_warn_and_unknown_ones_raise(model):
+    audio = synth.noise_clip(0)[: 5 * 16000]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        segs, _ = model.transcribe(audio, language="zh", beam_size=1, temperature=0.0, max_new_tokens=4,
+                                   hotwords="台灣", repetition_penalty=1.2, length_penalty=1, patience=1.0)
+        list(segs)
+    msgs = [str(x.message) for x in w]
+    assert any("hotwords" in m for m in msgs) and any("repetition_penalty" in m for m in msgs)
+    assert not any("length_penalty" in m or "patience" in m for m in msgs)      # neutral values are fine
+    with pytest.raises(TypeError):
+        model.transcribe(audio, language="zh", beam=5)
