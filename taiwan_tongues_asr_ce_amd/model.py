@@ -71,10 +71,45 @@ LANGUAGES = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk 
              "tg sd gu am yi lo uz fo ht ps tk nn mt sa lb my bo tl mg as tt haw ln ha ba jw su yue").split()
 
 
+def _to_mono_16k(x: np.ndarray, sr: int, sampling_rate: int) -> np.ndarray:
+    if sr != sampling_rate:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(sr, sampling_rate)
+        x = resample_poly(x, sampling_rate // g, sr // g)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
 def decode_audio(path: str, sampling_rate: int = SAMPLE_RATE) -> np.ndarray:
-    """Path -> mono float32 @16 kHz.  RIFF/WAV PCM only (stdlib `wave`); the reference decodes with
-    librosa / PyAV (asr_core.py:156, faster-whisper decode_audio), neither of which is installed here."""
+    """Path -> mono float32 @16 kHz.  RIFF/WAV PCM through the stdlib; other containers through soundfile / librosa /
+    PyAV when the host has one (the reference decodes with librosa / PyAV: asr_core.py:156, faster-whisper decode_audio)."""
     import wave
+    if not path.lower().endswith((".wav", ".wave")):
+        # compressed containers (asr_core.py:118 also globs mp3/flac/m4a/aac): use whichever decoder the host has —
+        # none is installed in the build image, so these branches are unexercised here and the error below is what
+        # the folder tool records per file
+        try:
+            import soundfile as sf  # type: ignore
+            x, sr = sf.read(path, dtype="float32", always_2d=True)
+            return _to_mono_16k(x.mean(axis=1), sr, sampling_rate)
+        except ImportError:
+            pass
+        except Exception:
+            pass  # format not handled by libsndfile: try the next decoder
+        try:
+            import librosa  # type: ignore
+            x, _ = librosa.load(path, sr=sampling_rate, mono=True)
+            return np.ascontiguousarray(x, dtype=np.float32)
+        except ImportError:
+            pass
+        try:
+            import av  # type: ignore
+            with av.open(path) as container:
+                resampler = av.audio.resampler.AudioResampler(format="s16", layout="mono", rate=sampling_rate)
+                chunks = [f.to_ndarray().reshape(-1) for frame in container.decode(audio=0) for f in resampler.resample(frame)]
+            return (np.concatenate(chunks).astype(np.float32) / 32768.0) if chunks else np.zeros(0, np.float32)
+        except ImportError:
+            raise RuntimeError(f"{path}: no decoder for this container (install soundfile, librosa or av); RIFF/WAV needs none")
     with wave.open(path, "rb") as w:
         n_ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
         raw = w.readframes(n)
