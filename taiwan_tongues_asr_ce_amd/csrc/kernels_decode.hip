@@ -48,8 +48,7 @@ struct RowRule {  // per-row view of the rules at this step
   int n, last_is_ts, pen_is_ts, ts_floor;  // ts_floor: timestamps < ts_floor are masked (or 0)
 };
 
-__device__ __forceinline__ bool masked(int i, const RowRule& r, const RuleParams& p, const uint8_t* __restrict__ mask) {
-  uint8_t mk = mask[i];
+__device__ __forceinline__ bool masked_mk(uint32_t mk, int i, const RowRule& r, const RuleParams& p) {
   if (mk & 1) return true;
   if (r.n == 0 && (mk & 2)) return true;
   if (p.suppress_eot && i == p.eot) return true;
@@ -67,6 +66,23 @@ __device__ __forceinline__ bool masked(int i, const RowRule& r, const RuleParams
     }
   }
   return false;
+}
+
+__device__ __forceinline__ bool masked(int i, const RowRule& r, const RuleParams& p, const uint8_t* __restrict__ mask) {
+  return masked_mk(mask[i], i, r, p);
+}
+// Visit every element of a logits row with 16-byte loads (row and mask are 16-byte aligned, ldv % 4 == 0): thread t takes
+// elements 4t..4t+3, 4(t+1024).. ; the < 4 tail elements go to the first threads.  f(i, value, mask byte).
+template <class F>
+__device__ __forceinline__ void for_each_logit(const float* __restrict__ row, const uint8_t* __restrict__ mask, int V, int tid,
+                                               F&& f) {
+  const int V4 = V & ~3;
+  for (int i = tid * 4; i < V4; i += 4096) {
+    const float4 v = *(const float4*)(row + i);
+    const uint32_t m = *(const uint32_t*)(mask + i);
+    f(i, v.x, m & 0xff); f(i + 1, v.y, (m >> 8) & 0xff); f(i + 2, v.z, (m >> 16) & 0xff); f(i + 3, v.w, m >> 24);
+  }
+  if (V4 + tid < V) f(V4 + tid, row[V4 + tid], (uint32_t)mask[V4 + tid]);
 }
 
 struct ArgMax { float v; int i; };
@@ -124,16 +140,15 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 
   ArgMax a_txt{-INFINITY, 0x7fffffff}, a_ts{-INFINITY, 0x7fffffff};
   float raw_max = -INFINITY;
-  for (int i = tid; i < p.V; i += 1024) {
-    float v = row[i];
+  for_each_logit(row, st.mask, p.V, tid, [&](int i, float v, uint32_t mbyte) {
     raw_max = fmaxf(raw_max, v);
-    bool mk = masked(i, r, p, st.mask);
+    const bool mk = masked_mk(mbyte, i, r, p);
     if (out_rows) out_rows[(int64_t)b * p.V + i] = mk ? -INFINITY : v;
     if (!mk) {
       ArgMax c{v, i};
       if (p.timestamps && i >= tb) a_ts = am_merge(a_ts, c); else a_txt = am_merge(a_txt, c);
     }
-  }
+  });
   a_txt = am_wave(a_txt);
   a_ts = am_wave(a_ts);
   raw_max = wave_max(raw_max);
@@ -151,14 +166,13 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   const int i_txt = s_i[0], i_ts = s_i[1];
   const float mx_all = fmaxf(mx_txt, mx_ts);
   float sum_txt = 0.f, sum_ts = 0.f, sum_raw = 0.f;
-  for (int i = tid; i < p.V; i += 1024) {
-    float v = row[i];
+  for_each_logit(row, st.mask, p.V, tid, [&](int i, float v, uint32_t mbyte) {
     if (want_ns) sum_raw += __expf(v - mx_raw);
-    if (!masked(i, r, p, st.mask)) {
+    if (!masked_mk(mbyte, i, r, p)) {
       float e = __expf(v - mx_all);
       if (p.timestamps && i >= tb) sum_ts += e; else sum_txt += e;
     }
-  }
+  });
   sum_txt = wave_sum(sum_txt); sum_ts = wave_sum(sum_ts); sum_raw = wave_sum(sum_raw);
   __syncthreads();
   if (lane == 0) { s_sum[0][wave] = sum_txt; s_sum[1][wave] = sum_ts; s_sum[2][wave] = sum_raw; }
@@ -277,11 +291,10 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict
   r.ts_floor = (lts >= 0) ? ((r.last_is_ts && !r.pen_is_ts) ? lts : lts + 1) : 0;
   // pass 1: maxima of the text / timestamp ranges (masked) and of the raw row
   float m_txt = -INFINITY, m_ts = -INFINITY, m_raw = -INFINITY;
-  for (int i = tid; i < p.V; i += 1024) {
-    const float v = row[i];
+  for_each_logit(row, st.mask, p.V, tid, [&](int i, float v, uint32_t mbyte) {
     m_raw = fmaxf(m_raw, v);
-    if (!masked(i, r, p, st.mask)) { if (p.timestamps && i >= tb) m_ts = fmaxf(m_ts, v); else m_txt = fmaxf(m_txt, v); }
-  }
+    if (!masked_mk(mbyte, i, r, p)) { if (p.timestamps && i >= tb) m_ts = fmaxf(m_ts, v); else m_txt = fmaxf(m_txt, v); }
+  });
   m_txt = wave_max(m_txt); m_ts = wave_max(m_ts); m_raw = wave_max(m_raw);
   if (lane == 0) { s_sum[0][wave] = m_txt; s_sum[1][wave] = m_ts; s_sum[2][wave] = m_raw; }
   __syncthreads();
@@ -294,11 +307,10 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict
   const float mx_txt = s_f[0], mx_ts = s_f[1], mx_raw = s_f[2], mx_all = fmaxf(mx_txt, mx_ts);
   // pass 2: exp sums
   float sum_txt = 0.f, sum_ts = 0.f, sum_raw = 0.f;
-  for (int i = tid; i < p.V; i += 1024) {
-    const float v = row[i];
+  for_each_logit(row, st.mask, p.V, tid, [&](int i, float v, uint32_t mbyte) {
     if (out_ns) sum_raw += __expf(v - mx_raw);
-    if (!masked(i, r, p, st.mask)) { const float e = __expf(v - mx_all); if (p.timestamps && i >= tb) sum_ts += e; else sum_txt += e; }
-  }
+    if (!masked_mk(mbyte, i, r, p)) { const float e = __expf(v - mx_all); if (p.timestamps && i >= tb) sum_ts += e; else sum_txt += e; }
+  });
   sum_txt = wave_sum(sum_txt); sum_ts = wave_sum(sum_ts); sum_raw = wave_sum(sum_raw);
   __syncthreads();
   if (lane == 0) { s_sum[0][wave] = sum_txt; s_sum[1][wave] = sum_ts; s_sum[2][wave] = sum_raw; }
@@ -317,14 +329,14 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict
   // k rounds of masked argmax, excluding the ids already taken
   for (int round = 0; round < k; ++round) {
     ArgMax best{-INFINITY, 0x7fffffff};
-    for (int i = tid; i < p.V; i += 1024) {
-      if (force_ts && i < tb) continue;
-      if (masked(i, r, p, st.mask)) continue;
+    for_each_logit(row, st.mask, p.V, tid, [&](int i, float v, uint32_t mbyte) {
+      if (force_ts && i < tb) return;
+      if (masked_mk(mbyte, i, r, p)) return;
       bool taken = false;
       for (int c = 0; c < round; ++c) taken |= (s_chosen[c] == i);
-      if (taken) continue;
-      best = am_merge(best, ArgMax{row[i], i});
-    }
+      if (taken) return;
+      best = am_merge(best, ArgMax{v, i});
+    });
     best = am_wave(best);
     if (lane == 0) s_am[0][wave] = best;
     __syncthreads();
