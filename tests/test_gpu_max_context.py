@@ -22,19 +22,16 @@ def _engine(name, compute, max_batch):
 
 
 def _teacher_forced_gap(enc, prompt, tokens, W, dims, rules):
-    """max over positions of (oracle's best allowed logit - logit of the engine's token)."""
+    """max over positions of (oracle's best allowed logit - logit of the engine's token); ONE causal oracle pass over
+    prompt + tokens gives the logits of every position."""
     xkv = R.cross_kv(enc, W, dims)
-    cache = R.SelfCache.empty(dims.dec_layers)
-    logits = None
-    for t in prompt:
-        logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, W, dims)[:, 0]
+    seq = list(prompt) + list(tokens[:-1])
+    logits = R.decoder_forward(torch.tensor([seq]), R.SelfCache.empty(dims.dec_layers), xkv, W, dims)[0]
     worst = 0.0
     for i, t in enumerate(tokens):
-        s = R.apply_rules(logits[0], tokens[:i], rules)
+        s = R.apply_rules(logits[len(prompt) - 1 + i], tokens[:i], rules)
         assert s[t] > -np.inf, f"position {i}: engine emitted a masked token"
         worst = max(worst, float(s.max() - s[t]))
-        if i + 1 < len(tokens):
-            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, W, dims)[:, 0]
     return worst
 
 

@@ -128,16 +128,13 @@ def test_prefill_bf16_consistent_with_token_by_token(setup):
 
     def score(tokens, b):
         xkv = R.cross_kv(enc[b:b + 1], Wb, dims)
-        cache = R.SelfCache.empty(dims.dec_layers)
-        logits = None
-        for t in prompt:
-            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
+        seq = list(prompt) + list(tokens[:-1])
+        logits = R.decoder_forward(torch.tensor([seq]), R.SelfCache.empty(dims.dec_layers), xkv, Wb, dims)[0]
         total = 0.0
         for i, t in enumerate(tokens):
-            s = R.apply_rules(logits[0], tokens[:i], rules)
+            s = R.apply_rules(logits[len(prompt) - 1 + i], tokens[:i], rules)
             assert s[t] > -np.inf
             total += float(torch.log_softmax(torch.as_tensor(s), -1)[t])
-            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
         return total
 
     for b in range(3):
