@@ -229,19 +229,36 @@ class WhisperModel:
         probs = [(LANGUAGES[i], float(p[i])) for i in order]
         return probs[0][0], probs[0][1], probs
 
-    def _prompt(self, lang_tok: int, task: str, without_timestamps: bool, prev: Sequence[int]) -> Tuple[List[int], int]:
+    def _prompt(self, lang_tok: int, task: str, without_timestamps: bool, prev: Sequence[int],
+                hotwords: Optional[Sequence[int]] = None, prefix: Optional[Sequence[int]] = None) -> Tuple[List[int], int]:
+        """faster-whisper get_prompt: [<|startofprev|> hotwords… previous…] <|startoftranscript|> <|lang|> <|task|>
+        [<|notimestamps|>] [<|0.00|> prefix…]; hotwords are dropped when a prefix is given, each part is capped at
+        n_text_ctx // 2 - 1 tokens.  Returns (prompt, position of <|startoftranscript|>)."""
         st = self.special
+        half = self.dims.n_text_ctx // 2 - 1
         p: List[int] = []
-        if prev:
+        use_hot = bool(hotwords) and not prefix
+        hot = list(hotwords)[:half] if use_hot else []
+        pre = list(prefix)[:half] if prefix else []
+        # hotwords + previous text + prefix could exceed the 448-token context (faster-whisper does not guard this
+        # corner): the oldest previous tokens give way so that at least 32 positions stay free for the transcript
+        fixed = 1 + len(hot) + 3 + int(without_timestamps) + (len(pre) + (0 if without_timestamps else 1) if pre else 0)
+        keep_prev = max(0, min(half, self.dims.n_text_ctx - 32 - fixed))
+        prev = list(prev)[-keep_prev:] if keep_prev and prev else []
+        if prev or use_hot:
             p.append(st.sot_prev)
-            p.extend(list(prev)[-(self.dims.n_text_ctx // 2 - 1):])
+            p.extend(hot)
+            p.extend(prev)
         sot_index = len(p)
         p.append(st.sot)
-        if self.is_multilingual or True:
-            p.append(lang_tok)
-            p.append(st.translate if task == "translate" else st.transcribe)
+        p.append(lang_tok)
+        p.append(st.translate if task == "translate" else st.transcribe)
         if without_timestamps:
             p.append(st.no_timestamps)
+        if pre:
+            if not without_timestamps:
+                p.append(st.timestamp_begin)
+            p.extend(pre)
         return p, sot_index
 
     def _split_segments(self, tokens: List[int], seek: int, n_frames_window: int, time_offset: float,
@@ -293,13 +310,13 @@ class WhisperModel:
         # faster-whisper options this build does not implement are never silently ignored when they differ from
         # their defaults (the reference call sites pass none of them)
         neutral = {"patience": None, "vad_parameters": None, "vad_speech_prob_fn": None, "length_penalty": 1, "repetition_penalty": 1,
-                   "no_repeat_ngram_size": 0, "prefix": None, "hotwords": None, "clip_timestamps": "0",
+                   "no_repeat_ngram_size": 0, "clip_timestamps": "0",
                    "hallucination_silence_threshold": None, "prompt_reset_on_temperature": 0.5, "suppress_tokens": [-1],
                    "prepend_punctuations": alignment.PREPEND_PUNCTUATIONS, "append_punctuations": alignment.APPEND_PUNCTUATIONS,
                    "multilingual": False, "language_detection_threshold": 0.5, "language_detection_segments": 1,
                    "chunk_length": None, "log_progress": False}
         for k, v in kwargs.items():
-            if k in ("patience", "vad_parameters", "vad_speech_prob_fn"):
+            if k in ("patience", "vad_parameters", "vad_speech_prob_fn", "hotwords", "prefix"):
                 continue
             if k not in neutral:
                 raise TypeError(f"transcribe() got an unexpected keyword argument {k!r}")
@@ -355,7 +372,8 @@ class WhisperModel:
                                            without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
                                            max_initial_timestamp, suppress_blank, beam_size, kwargs.get("patience", 1.0),
                                            tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),),
-                                           best_of, compression_ratio_threshold, bool(word_timestamps))
+                                           best_of, compression_ratio_threshold, bool(word_timestamps),
+                                           kwargs.get("hotwords"), kwargs.get("prefix"))
         if chunks is not None:
             segments = vad.restore_speech_timestamps(segments, chunks)
         return segments, info
@@ -466,8 +484,9 @@ class WhisperModel:
 
     def _params(self, language, task, condition, without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
                 max_initial_timestamp, suppress_blank, beam_size, patience, temperatures, best_of,
-                compression_ratio_threshold, word_timestamps) -> dict:
-        return dict(language=language, lang_tok=self._lang_token(language), task=task, condition=condition,
+                compression_ratio_threshold, word_timestamps, hotwords=None, prefix=None) -> dict:
+        enc = lambda t: self.tokenizer.encode(" " + t.strip()) if t else None
+        return dict(hotwords_tokens=enc(hotwords), prefix_tokens=enc(prefix), language=language, lang_tok=self._lang_token(language), task=task, condition=condition,
                     without_timestamps=without_timestamps, max_new=max_new_tokens or (self.dims.n_text_ctx // 2),
                     no_speech_threshold=no_speech_threshold, log_prob_threshold=log_prob_threshold,
                     max_initial_timestamp=max_initial_timestamp, suppress_blank=suppress_blank, beam_size=beam_size,
@@ -477,11 +496,11 @@ class WhisperModel:
     def _generate_segments(self, audio, language, task, condition, initial_prompt, without_timestamps, max_new_tokens,
                            no_speech_threshold, log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size=1,
                            patience=1.0, temperatures=(0.0,), best_of=5, compression_ratio_threshold=2.4,
-                           word_timestamps=False) -> Iterator[Segment]:
+                           word_timestamps=False, hotwords=None, prefix=None) -> Iterator[Segment]:
         eng = self.engine
         p = self._params(language, task, condition, without_timestamps, max_new_tokens, no_speech_threshold,
                          log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size, patience, temperatures, best_of,
-                         compression_ratio_threshold, word_timestamps)
+                         compression_ratio_threshold, word_timestamps, hotwords, prefix)
         fs = self._new_file_state(audio, initial_prompt)
         while fs["seek"] < fs["n_total"]:
             seek = fs["seek"]
@@ -489,7 +508,8 @@ class WhisperModel:
             eng.set_audio_ctx(0)
             eng.log_mel([audio[seek * HOP: seek * HOP + self.n_window]], want_output=False)
             eng.encode(1)
-            prompt, sot_index = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:])
+            prompt, sot_index = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:],
+                                             p["hotwords_tokens"], p["prefix_tokens"] if seek == 0 else None)
             attempt = self._decode_with_fallback(prompt, self._window_opts(len(prompt), sot_index, p), seek, p)
             yield from self._finish_window(fs, 0, attempt, win_frames, p)
 
@@ -499,7 +519,8 @@ class WhisperModel:
                         max_new_tokens: Optional[int] = None, no_speech_threshold: Optional[float] = 0.6,
                         log_prob_threshold: Optional[float] = -1.0, max_initial_timestamp: float = 1.0,
                         suppress_blank: bool = True, temperature: Union[float, Sequence[float]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
-                        best_of: int = 5, compression_ratio_threshold: Optional[float] = 2.4, patience: float = 1.0
+                        best_of: int = 5, compression_ratio_threshold: Optional[float] = 2.4, patience: float = 1.0,
+                        hotwords: Optional[str] = None, prefix: Optional[str] = None
                         ) -> List[Tuple[List[Segment], TranscriptionInfo]]:
         """Several FILES in lock step: every round takes the next 30-s window of each unfinished file and runs them as
         ONE engine pass (log-mel, encoder, beam search with one previous-text prompt per file), so a folder is
@@ -512,7 +533,7 @@ class WhisperModel:
         temps = tuple(temperature) if isinstance(temperature, (list, tuple)) else (float(temperature),)
         p = self._params(language, task, condition_on_previous_text, without_timestamps, max_new_tokens, no_speech_threshold,
                          log_prob_threshold, max_initial_timestamp, suppress_blank, beam, patience, temps, best_of,
-                         compression_ratio_threshold, bool(word_timestamps))
+                         compression_ratio_threshold, bool(word_timestamps), hotwords, prefix)
         files = []
         for a in audios:
             a = decode_audio(a) if isinstance(a, str) else np.asarray(a)
@@ -533,7 +554,8 @@ class WhisperModel:
                 eng.encode(len(group))
                 prompts, sots = [], []
                 for fs in group:
-                    pr, si = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:])
+                    pr, si = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:],
+                                          p["hotwords_tokens"], p["prefix_tokens"] if fs["seek"] == 0 else None)
                     prompts.append(pr)
                     sots.append(si)
                 # one budget for the pass: the shortest prompt's; the 448-token context cuts longer prompts' rows short

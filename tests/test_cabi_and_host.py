@@ -195,3 +195,19 @@ def test_hf_directory_reader_safetensors_and_bin(tmp_path):
         (tmp_path / "empty").mkdir()
         (tmp_path / "empty" / "config.json").write_text(json.dumps(cfg), encoding="utf-8")
         list(_read_hf_dir(str(tmp_path / "empty"))[1])
+
+
+def test_prompt_with_hotwords_and_prefix():
+    m = _bare_model()
+    st = m.special
+    hot, pre, prev = [900, 901], [700, 701, 702], [500, 501]
+    p, sot = m._prompt(st.lang_zh, "transcribe", False, prev, hot, None)
+    assert p == [st.sot_prev, 900, 901, 500, 501, st.sot, st.lang_zh, st.transcribe] and sot == 5
+    p, sot = m._prompt(st.lang_zh, "transcribe", False, [], hot, None)          # hotwords alone still open with <|startofprev|>
+    assert p == [st.sot_prev, 900, 901, st.sot, st.lang_zh, st.transcribe] and sot == 3
+    p, sot = m._prompt(st.lang_zh, "transcribe", False, prev, hot, pre)         # a prefix drops the hotwords
+    assert p == [st.sot_prev, 500, 501, st.sot, st.lang_zh, st.transcribe, st.timestamp_begin, 700, 701, 702] and sot == 3
+    p, sot = m._prompt(st.lang_zh, "transcribe", True, [], None, pre)
+    assert p == [st.sot, st.lang_zh, st.transcribe, st.no_timestamps, 700, 701, 702] and sot == 0
+    p, _ = m._prompt(st.lang_zh, "transcribe", False, list(range(1000, 1400)), list(range(2000, 2400)), None)
+    assert len(p) == 448 - 32 and p[1:224] == list(range(2000, 2223)) and p[224] == 1400 - (448 - 32 - 227)   # previous text gives way

@@ -261,10 +261,34 @@ def test_unsupported_options_warn_and_unknown_ones_raise(model):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         segs, _ = model.transcribe(audio, language="zh", beam_size=1, temperature=0.0, max_new_tokens=4,
-                                   hotwords="台灣", repetition_penalty=1.2, length_penalty=1, patience=1.0)
+                                   no_repeat_ngram_size=3, repetition_penalty=1.2, length_penalty=1, patience=1.0)
         list(segs)
     msgs = [str(x.message) for x in w]
-    assert any("hotwords" in m for m in msgs) and any("repetition_penalty" in m for m in msgs)
+    assert any("no_repeat_ngram_size" in m for m in msgs) and any("repetition_penalty" in m for m in msgs)
     assert not any("length_penalty" in m or "patience" in m for m in msgs)      # neutral values are fine
     with pytest.raises(TypeError):
         model.transcribe(audio, language="zh", beam=5)
+
+
+def test_hotwords_and_prefix_reach_the_engine(model):
+    """hotwords / prefix are prompt-side options (faster-whisper get_prompt): the decode must equal the oracle's greedy
+    search on the prompt `_prompt` builds, and differ from the plain run."""
+    audio = synth.tonal_clip(6)[: 12 * 16000]
+    st = model.special
+    dims = R.Dims(**PRESETS["tiny"].as_dict())
+    W = R.to_torch(synth.state_dict(PRESETS["tiny"]))
+    enc = R.encoder_forward(torch.from_numpy(R.log_mel(audio, 80))[None], W, dims)
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
+    kw = dict(language="zh", beam_size=1, temperature=0.0, max_new_tokens=10, log_prob_threshold=None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = [t for s in model.transcribe(audio, **kw)[0] for t in s.tokens]
+        for extra in (dict(hotwords="台灣 語音"), dict(prefix="今天")):
+            got = [t for s in model.transcribe(audio, **kw, **extra)[0] if s.seek == 0 for t in s.tokens]
+            hot = model.tokenizer.encode(" " + extra["hotwords"]) if "hotwords" in extra else None
+            pre = model.tokenizer.encode(" " + extra["prefix"]) if "prefix" in extra else None
+            prompt, _ = model._prompt(st.lang_zh, "transcribe", False, [], hot, pre)
+            ref = [t for t in R.greedy_decode(enc, prompt, W, dims, rules, 10).tokens[0] if t != st.eot]
+            assert got == ref[: len(got)] and len(got) > 0 and got != plain
