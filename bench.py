@@ -5,8 +5,8 @@
 One "step" = the whole hot path over one batch of synthetic clips already resident in HBM:
 log-mel -> encoder -> cross-KV -> 4-token prompt + 128 greedy tokens (EOT suppressed so every run decodes
 the same length).  Weights are seeded synthetic tensors of the named geometry (no
-checkpoint exists offline).  Launch: `python bench.py` (1 GPU) or
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+checkpoint exists offline).  Launch: `python bench.py` (1 GPU), `python bench.py --gpus N` (spawns its own N rank
+processes) or `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -86,6 +86,96 @@ def cpu_baseline(dims, n_new: int, budget_layers: int = 2, budget_steps: int = 6
                        f"(CTranslate2 int8, api/file_asr.py:188) is not installable offline")}
 
 
+def cpu_baseline_full(dims, n_new: int):
+    """ONE complete run of the CPU oracle on the headline workload at B = 1: full large-v3 depth,
+    one 30-s clip, 4-token prompt + n_new greedy tokens with EOT suppressed.  Minutes of host time: run once with
+    `python bench.py --cpu-full` on the GPU box and cached under profiles/ (the default run reads the cache)."""
+    import torch
+    from oracle import whisper_ref as R
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import SpecialTokens
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    torch.set_grad_enabled(False)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    rd = R.Dims(**dims.as_dict())
+    W = R.to_torch(synth.state_dict(dims))
+    st = SpecialTokens.for_vocab(dims.vocab)
+    clip = synth.noise_clip(0)
+    t0 = time.perf_counter()
+    mel = torch.from_numpy(R.log_mel(clip, dims.n_mels))[None]
+    enc = R.encoder_forward(mel, W, rd)
+    t_enc = time.perf_counter() - t0
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, rd.vocab) + [st.eot], begin_suppress=[220, st.eot], timestamps=False)
+    ref = R.greedy_decode(enc, [st.sot, st.lang_zh, st.transcribe, st.no_timestamps], W, rd, rules, n_new)
+    total = time.perf_counter() - t0
+    return {"value": round(30.0 / total, 4), "unit": "audio-s/s", "cores": cores, "kind": "port", "seconds": round(total, 1),
+            "encoder_seconds": round(t_enc, 1), "tokens": len(ref.tokens[0]), "cpu": _cpu_model(),
+            "sample": f"oracle/whisper_ref.py, ONE full run: 1 clip x 30 s, all {dims.enc_layers}+{dims.dec_layers} layers, "
+                      f"4-token prompt + {n_new} greedy tokens, torch CPU f32, {cores} threads"}
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a bare shell (no torchrun environment): this parent process touches no GPU - it
+    only spawns the N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set exactly as
+    torch.distributed.run would) and relays rank 0's JSON line.  Nothing is exec'ed over an initialised GPU process."""
+    import socket
+    import subprocess
+    import torch
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < n:   # device_count() does not initialise the GPU
+        # fewer devices than ranks: the ranks share GPUs and talk over gloo (RCCL refuses two ranks per device).
+        # Plumbing check only - the line then says so in config.parallelism
+        env["TTASR_DIST_BACKEND"] = "gloo"
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    for line in out0.splitlines():      # rank 0 prints the ONE JSON line; library chatter on its stdout is not relayed
+        if line.startswith("{"):
+            print(line, flush=True)
+    return max(abs(rc) for rc in rcs)
+
+
+def _host_greedy_prefix(eng, B, prompt, n_check, suppress, begin_suppress, eot):
+    """Recompute the first n_check greedy tokens of every row through the STEP API (ttasr_decode_step: raw logits to the
+    host, rules + first-maximum argmax applied here in numpy) on the cross-KV the last timed step left resident."""
+    eng.decode_reset(B)
+    logits = None
+    for t in prompt:
+        logits = eng.decode_step([t] * B)
+    sup = np.asarray(sorted(set(suppress) | {eot}), dtype=np.int64)     # benchmark mode: EOT suppressed
+    bsup = np.asarray(begin_suppress, dtype=np.int64)
+    out = np.zeros((B, n_check), dtype=np.int32)
+    for i in range(n_check):
+        lg = logits.copy()
+        lg[:, sup] = -np.inf
+        if i == 0:
+            lg[:, bsup] = -np.inf
+        nxt = lg.argmax(axis=1).astype(np.int32)
+        out[:, i] = nxt
+        if i + 1 < n_check:
+            logits = eng.decode_step(nxt.tolist())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +196,13 @@ def main():
                     help="opt-in serving configuration: this many independent engine contexts per GPU, each running the "
                          "whole step on its own batch of --batch clips from its own host thread (clips in flight per GPU "
                          "= contexts x batch; the latency-bound decode chains of one context fill the gaps of the other)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="run ONE full large-v3 B = 1 pass of the CPU oracle (minutes) and cache it as profiles/cpu_baseline_full.json")
+    ap.add_argument("--write-crc", action="store_true", help="record the token checksum of this run as the expected one")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -193,14 +289,15 @@ def main():
     assert toks.shape == (world * B * C_, args.new_tokens)
 
     logits_spread = None
-    if args.validate:
+    if args.validate or world > 1:
         from taiwan_tongues_asr_ce_amd.dist import gather_logits
         eng.log_mel([synth.noise_clip(0)], want_output=False)        # the SAME clip on every rank
         eng.encode(1)
         eng.decode_reset(1)
         all_lg = gather_logits(eng.decode_step([st.sot]), device=local)
         logits_spread = float(np.abs(all_lg - all_lg[0:1]).max())
-        if logits_spread > (2e-2 if args.compute == "bf16" else 1e-4):   # bf16: atomics reorder the last bits only
+        # every rank loaded the same broadcast bits and no kernel uses float atomics: the spread is expected to be exactly 0
+        if logits_spread > (2e-2 if args.compute == "bf16" else 1e-4):
             raise SystemExit(f"validation failed: first-step logits differ across ranks by {logits_spread}")
 
     # PCIe-inclusive variant (never `value`): the same step with the PCM handed over as a pinned host buffer
@@ -216,6 +313,42 @@ def main():
             hs.append(time.perf_counter() - ts)
         host_ms = float(np.median(hs)) * 1e3
         del pcm_host
+
+    # What ties the timed work to correct output (rank 0): (i) the first tokens of EVERY row of the last timed step are
+    # recomputed through a different route - the step API hands raw logits to the host, the rules and the first-maximum
+    # argmax run in numpy - on the cross-KV that step left resident, and must be identical (the engine is bit-
+    # reproducible: no float atomics); (ii) a CRC-32 of all B x new_tokens token ids against the value recorded for this
+    # configuration in profiles/bench_tokens_crc.json (a tripwire for skipped work / changed arithmetic; rewritten with
+    # --write-crc when a kernel change legitimately alters the last bits).  Logit-level parity of the same kernels
+    # against the oracle is the job of tests/ (test_gpu_full_size.py at this geometry).
+    check = None
+    if rank == 0 and C_ == 1:
+        import zlib
+        n_chk = min(8, args.new_tokens)
+        mine = np.asarray(toks[:B], dtype=np.int32)
+        again = one_pass(eng)            # also restores this rank's resident state after the validation probe
+        replay_equal = all(list(mine[b, :len(t)]) == list(t) for b, t in enumerate(again))
+        redo = _host_greedy_prefix(eng, B, prompt, n_chk, [opts.suppress[i] for i in range(opts.n_suppress)],
+                                   [opts.begin_suppress[i] for i in range(opts.n_begin_suppress)], st.eot)
+        crc = zlib.crc32(np.ascontiguousarray(mine).tobytes()) & 0xFFFFFFFF
+        key = f"{args.model}/b{B}/n{args.new_tokens}/{args.compute}"
+        crc_path = os.path.join(ROOT, "profiles", "bench_tokens_crc.json")
+        try:
+            with open(crc_path) as f:
+                known = json.load(f)
+        except Exception:
+            known = {}
+        if args.write_crc:
+            known[key] = crc
+            with open(crc_path, "w") as f:
+                json.dump(known, f, indent=1, sort_keys=True)
+        check = {"replay_bit_identical": bool(replay_equal), "prefix_tokens_recomputed_via_step_api": n_chk, "prefix_equal": bool(np.array_equal(redo, mine[:, :n_chk])),
+                 "tokens_crc32": crc, "expected_crc32": known.get(key), "crc_match": (known.get(key) == crc) if key in known else None}
+        if not check["prefix_equal"] or not replay_equal:
+            raise SystemExit(f"output check failed: greedy tokens of the timed step differ from the step-API recomputation\n"
+                             f"{mine[:2, :n_chk].tolist()} vs {redo[:2].tolist()}")
+        # the recomputation moved the decode state: rebuild the step's state for the kernel measurements below
+        one_pass(eng)
 
     if rank == 0:
         esz = 2 if args.compute == "bf16" else 4
@@ -233,6 +366,7 @@ def main():
             pass
         roof = {"kernel": "cross_attn_decode_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "traffic_source": "profiles/xattn_pmc.json (static: separate rocprofv3 --pmc passes, not re-measured by this run)",
                 "avg_launch_us": round(k["ms"] * 1e3, 2), "bytes_per_launch": k["bytes"]}
         # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time
         # (a first untimed pass brings the clocks back up after the latency-bound decode phase)
@@ -262,15 +396,29 @@ def main():
                                    f"clips per GPU resident in HBM, log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
                        "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens,
-                       "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else ""),
+                       "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else "") +
+                                      (" (ranks share GPUs over gloo: plumbing check, not a scaling number)"
+                                       if world > torch.cuda.device_count() else ""),
                        "rank_logits_spread": logits_spread, "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
                      "frac": round(enc_tf / 2500.0, 4), "pmc_mfma_busy_frac": pmc_busy},
         }
+        if check is not None:
+            out["output_check"] = check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, args.new_tokens)
+            full_path = os.path.join(ROOT, "profiles", "cpu_baseline_full.json")
+            if args.cpu_full:
+                full = cpu_baseline_full(dims, args.new_tokens)
+                with open(full_path, "w") as f:
+                    json.dump(full, f, indent=1)
+            try:   # the one complete B = 1 run, measured once on a GPU box's host and cached
+                with open(full_path) as f:
+                    out["cpu_baseline"]["full_run_cached"] = json.load(f)
+            except Exception:
+                pass
         if world == 1 and C_ == 1 and args.more_in_flight:
             # Side measurement, NOT `value`: the same step with a second independent context passing its own batch of
             # B clips concurrently (2 x B clips in flight).  One context's latency-bound decode chain leaves most of the

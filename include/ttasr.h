@@ -88,6 +88,15 @@ const char* ttasr_version(void);
 /* One tensor, float32 host data, HF state-dict name (model.encoder.conv1.weight, ...).  The engine
  * converts to its device layout (bf16 cast, QKV fusion, conv tap re-ordering, q pre-scaling by 1/8). */
 int ttasr_load_tensor(ttasr_ctx* ctx, const char* name, const float* data_host, const int64_t* dims, int32_t ndim);
+/* The same for a tensor that is already in DEVICE memory of this context's GPU (e.g. the bucket an RCCL broadcast just
+ * filled: multi-GPU start-up moves every weight GPU-to-GPU over xGMI, in bf16 where the engine stores bf16, and never
+ * stages it through a host): data_dev holds float32 (TTASR_DTYPE_F32) or raw bfloat16 bits (TTASR_DTYPE_BF16) in the
+ * HF layout.  Must be complete (the caller's stream synchronised) when the call is made.  The reference's
+ * WhisperModel(..., device="cuda") does this copy inside CTranslate2 (asr_core.py:141). */
+#define TTASR_DTYPE_F32 0
+#define TTASR_DTYPE_BF16 1
+int ttasr_load_tensor_device(ttasr_ctx* ctx, const char* name, const void* data_dev, int32_t dtype, const int64_t* dims,
+                             int32_t ndim);
 /* Checks every tensor arrived; must precede any compute call. */
 int ttasr_finalize_weights(ttasr_ctx* ctx);
 

@@ -234,6 +234,48 @@ def golden_align():
     print("align.npz", {k: v.shape for k, v in out.items() if "ts_" in k or "weights" in k})
 
 
+def golden_bf16():
+    """Golden set G5: the SAME tiny-geometry model with every parameter cast to bfloat16 and HF's
+    own bf16 arithmetic (residual stream, LayerNorm and logits all in bf16) - the precision regime of the reference's
+    GPU path (asr_core.py:141 float16; this build measures in bf16).  Stored per greedy step and clip: the token HF picks,
+    and the top-2 margin of the PROCESSED scores, so a bf16 engine can be held to token equality wherever the reference
+    itself is not within rounding distance of a tie."""
+    dims = PRESETS["tiny"]
+    model, st = hf_model(dims, dtype=torch.bfloat16)
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    pcm = [synth.noise_clip(0), synth.tonal_clip(1), synth.noise_clip(2), synth.burst_clip(3)]
+    mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
+    enc = model.model.encoder(torch.from_numpy(mel).to(torch.bfloat16)).last_hidden_state
+    suppress = list(NON_SPEECH_TOKENS_MULTI) + [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]
+    begin_suppress = [220, st.eot]
+    out = dict(clips=np.array(["noise0", "tonal1", "noise2", "burst3"]), suppress=np.array(suppress),
+               begin_suppress=np.array(begin_suppress), enc_stride=enc[:, ::25, ::3].float().numpy())
+    for tag, prompt, ts in (("ts", [st.sot, st.lang_zh, st.transcribe], True),
+                            ("nots", [st.sot, st.lang_zh, st.transcribe, st.no_timestamps], False)):
+        raw, toks, _, _ = hf_greedy(model, st, enc, prompt, 24, ts, suppress, begin_suppress)
+        procs = hf_processors(st, len(prompt), ts, suppress, begin_suppress)
+        ids = torch.tensor([prompt] * len(pcm), dtype=torch.long)
+        margins, second = [], []
+        for i in range(toks.shape[0]):
+            s = torch.from_numpy(raw[i]).clone()
+            for p in procs:
+                s = p(ids, s)
+            chosen = torch.from_numpy(toks[i])                        # bf16 logits hold exact ties: argmax = first maximum
+            s_chosen = s.gather(1, chosen[:, None])[:, 0]
+            assert (s_chosen == s.max(-1).values).all()
+            others = s.scatter(1, chosen[:, None], float("-inf"))
+            margins.append((s_chosen - others.max(-1).values).numpy())
+            second.append(others.argmax(-1).numpy())
+            ids = torch.cat([ids, torch.from_numpy(toks[i])[:, None]], dim=1)
+        out[f"{tag}_prompt"] = np.array(prompt)
+        out[f"{tag}_tokens"] = toks
+        out[f"{tag}_margin"] = np.stack(margins).astype(np.float32)
+        out[f"{tag}_runner_up"] = np.stack(second)
+        out[f"{tag}_logits_stride"] = raw[:, :, ::97]
+        print("tiny bf16", tag, toks.T.tolist()[0][:10], "min margin", float(np.stack(margins).min()))
+    np.savez_compressed(os.path.join(OUT, "tiny_bf16.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_mel()
@@ -241,3 +283,4 @@ if __name__ == "__main__":
     golden_micro()
     golden_tiny()
     golden_align()
+    golden_bf16()

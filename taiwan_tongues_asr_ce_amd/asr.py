@@ -34,8 +34,10 @@ class MI355XWhisperASR(ASRInterface):
         model_path = kwargs.get("model_path") or model_size
         device = kwargs.get("device", "cuda")
         compute_type = kwargs.get("compute_type", "float16")   # api/config.py:11-12
+        # decode rows: the adapter's default call is beam 5 with a best_of-5 temperature fallback (faster_whisper_asr.py:139-149),
+        # so the model needs at least that many rows or transcribe() refuses the beam
         self.asr_pipeline = WhisperModel(model_path, device=device, compute_type=compute_type,
-                                         max_batch=kwargs.get("max_batch", 1))
+                                         max_batch=max(8, int(kwargs.get("max_batch", 8))))
         # health-check attributes (faster_whisper_asr.py:111-114, streaming_asr.py:455-463)
         self.device, self.compute_type, self.model_size, self.model_path = device, compute_type, model_size, model_path
         self.default_transcribe_kwargs = {  # faster_whisper_asr.py:139-149
@@ -51,7 +53,9 @@ class MI355XWhisperASR(ASRInterface):
             kw["language"] = "zh"  # faster_whisper_asr.py:161
             import warnings
             with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
+                # only the known, documented degradation is silenced per utterance (it is logged once at start-up by the
+                # server): anything else - an option that is ignored, a beam that does not fit - stays visible
+                warnings.filterwarnings("ignore", message="vad_filter=True")
                 segments, info = self.asr_pipeline.transcribe(audio, **kw)
                 segments = list(segments)
             if len(segments) == 0:

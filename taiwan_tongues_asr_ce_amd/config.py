@@ -73,15 +73,16 @@ class SpecialTokens:
     no_timestamps: int
     timestamp_begin: int
     lang_zh: int
+    sot_lm: int = -1   # <|startoflm|> (sot_prev - 1 in the released vocabularies); -1: the vocabulary has none
 
     @staticmethod
     def for_vocab(vocab: int) -> "SpecialTokens":
         if vocab == 51866:  # large-v3 family: 100 languages
             return SpecialTokens(eot=50257, sot=50258, transcribe=50360, translate=50359, sot_prev=50362,
-                                 no_speech=50363, no_timestamps=50364, timestamp_begin=50365, lang_zh=50260)
+                                 no_speech=50363, no_timestamps=50364, timestamp_begin=50365, lang_zh=50260, sot_lm=50361)
         if vocab == 51865:  # multilingual tiny..large-v2: 99 languages
             return SpecialTokens(eot=50257, sot=50258, transcribe=50359, translate=50358, sot_prev=50361,
-                                 no_speech=50362, no_timestamps=50363, timestamp_begin=50364, lang_zh=50260)
+                                 no_speech=50362, no_timestamps=50363, timestamp_begin=50364, lang_zh=50260, sot_lm=50360)
         # synthetic small vocabularies (micro): carve the specials from the top of the range so the
         # processors still see "text < eot < specials < timestamps".
         ts = vocab - 64  # 64 timestamp tokens

@@ -76,10 +76,41 @@ bool gemm_bf16_v3_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
+// decode-step LayerNorm, one workgroup per row (kernels_misc.hip), that first completes the residual row:
+//   slab form:  x_out[row] = x[row] + bias + slab[0][row] + ... + slab[n_slab-1][row]   (fixed order, no atomics)
+//   embed form (tok != nullptr): x_out[row] = emb[tok[row]] + pos[*step]
+//   n_slab == 0 and tok == nullptr: plain LayerNorm of x
+struct LnPre {
+  const float* bias = nullptr;   // [d]
+  const float* slab = nullptr;   // [n_slab][slab_stride] f32 partial tiles of the preceding K-split residual GEMM
+  int n_slab = 0;                // <= 16
+  int64_t slab_stride = 0;
+  float* x_out = nullptr;        // [rows][d] updated residual rows (may alias x)
+  const int32_t* tok = nullptr;  // [rows]
+  const int32_t* step = nullptr; // [1]
+  const void* emb = nullptr;     // T [V][d]
+  const void* pos = nullptr;     // T [n_text_ctx][d]
+};
+template <typename T>
+void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const LnPre& pre,
+                           hipStream_t s);
+
+// K-split partial results of a decode GEMM handed to an attention kernel instead of T rows: value = round_T(bias +
+// slab[0] + ... + slab[n-1]) (slab order, bit-reproducible); n == 0 means "read the T rows as before"
+struct SlabIn {
+  const float* slab = nullptr;  // [n][stride] f32, row-major [rows][ld] inside a slab
+  const float* bias = nullptr;  // [ld]
+  int n = 0;
+  int64_t stride = 0;
+  int ld = 0;
+};
 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
 void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s);
-bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s);
+// ksplit > 1 (from gemm_skinny_ksplit): workgroup (nb, ks) writes its partial tile to slab[ks]; bias is the consumer's
+bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit = 1,
+                        float* slab = nullptr, int64_t slab_stride = 0);
+int gemm_skinny_ksplit(int B, int N, int K, int want);
 // mel
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
                 const float* filters /*[201][n_mels]*/, const float* dft_cos, const float* dft_sin /*[400]*/,
@@ -119,8 +150,6 @@ struct RuleParams {
   uint32_t seed;
 };
 template <typename T>
-void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s);
-template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel /*[H] dev*/,
                              float* probs /*[n_sel][rows][Tk]*/, hipStream_t s);
 void launch_token_logprob(const float* logits, int ldv, int V, const int32_t* target, float* out, int rows, hipStream_t s);
@@ -133,19 +162,25 @@ void launch_self_attn_prefill(const T* qkv /*[n_seq*npos][3d]*/, T* kv_pool, con
 template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
                              int64_t pool_layer_off, int identity_pages, int row0, const int32_t* step, T* out /*[B][d]*/, int B, int H,
-                             hipStream_t s);
+                             hipStream_t s, SlabIn sq = SlabIn{} /*qkv from K-split partial tiles*/);
 template <typename T>
 void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s);
 template <typename T>
 void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B / kv_div][H][Tk][64]*/, T* out, int B, int H,
                               int Tk, int kv_div, hipStream_t s,
-                              float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/);
+                              float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/,
+                              SlabIn sq = SlabIn{} /*q from K-split partial tiles*/);
+extern int g_xattn_variant;  // TTASR_XATTN: cross-attention kernel variant (A/B experiments)
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
 // per-row history state uploaded by the host)
 struct BeamRowState { const int32_t *n_sampled, *last_tok, *pen_tok, *last_ts; const uint8_t* mask; };
 void launch_beam_topk(const float* logits, BeamRowState st, RuleParams rp, int R, int k, float* out_lp /*[R][k]*/,
                       int32_t* out_id /*[R][k]*/, float* out_no_speech /*[R] or null*/, hipStream_t s);
-void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows /*nullable*/, hipStream_t s);
+// ticket != nullptr: the workgroup that finishes last (of `total_rows` over all select launches of the step) advances
+// *st.step, which replaces the separate advance launch
+void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows /*nullable*/, hipStream_t s,
+                   int32_t* ticket, int total_rows);
 void launch_advance(int32_t* step, hipStream_t s);
+void launch_prep_weight(const void* src, int src_bf16, float* dst, int64_t n, int64_t conv_in, float scale, hipStream_t s);
 template <typename T> void launch_cast(const float* in, T* out, int64_t n, hipStream_t s);
 template <typename T> void launch_uncast(const T* in, float* out, int64_t n, hipStream_t s);

@@ -67,7 +67,8 @@ struct ttasr_ctx {
         *dlnf_b = nullptr;
   std::vector<EncLayerW> enc;
   std::vector<DecLayerW> dec;
-  float* stage_f32 = nullptr;  // upload staging
+  float* stage_f32 = nullptr;  // upload staging (destination layout, f32)
+  float* stage_raw = nullptr;  // host uploads land here first (source layout)
   size_t stage_elems = 0;
 
   // mel constants
@@ -86,7 +87,15 @@ struct ttasr_ctx {
   int identity_pages = 1;    // page_table is the identity map (greedy): the self-attention kernel computes page ids
   int32_t* pairs_dev = nullptr;  // beam search: copy-on-write page pairs
   float* topk_lp = nullptr; int32_t* topk_id = nullptr; int32_t* row_state = nullptr;  // beam search scratch
-  int skip_mask = 0;  // TTASR_SKIP: timing experiments only (1 LN, 2 decode GEMMs, 4 self-attn, 8 cross-attn, 16 select)
+#ifdef TTASR_EXPERIMENTS
+  int skip_mask = 0;  // TTASR_SKIP (experiment builds only): 1 LN, 2 decode GEMMs, 4 self-attn, 8 cross-attn, 16 select
+#else
+  static constexpr int skip_mask = 0;  // release builds cannot drop work from the decode step
+#endif
+  float* slab = nullptr;      // [2 chains][16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
+  int ks_want[4] = {0, 0, 0, 0};  // TTASR_KS=d,q,qkv,fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
+  int gemm_force = 0;         // TTASR_GEMM=v1|v2|v3 (A/B testing of the encoder GEMM kernels)
+  bool no_flash = false;      // TTASR_NO_FLASH
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
   int max_new_alloc = 0, max_prompt_alloc = 0;
@@ -265,6 +274,7 @@ int build_weights(ttasr_ctx* c) {
   c->stage_elems = std::max<size_t>((size_t)V * d, (size_t)d * 3 * d);
   c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)F * d);
   TRY(dalloc(c, &c->stage_f32, c->stage_elems * 4, false));
+  TRY(dalloc(c, &c->stage_raw, c->stage_elems * 4, false));
   return 0;
 }
 
@@ -302,6 +312,7 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(alloc_mat(c, &c->datt, B * d));
   TRY(alloc_mat(c, &c->dmid, B * c->ffn));
   TRY(dalloc(c, &c->logits, (size_t)B * c->ldv * 4));
+  TRY(dalloc(c, &c->slab, (size_t)2 * 16 * B * 3 * d * 4));  // one region per half-batch chain
   c->max_new_alloc = c->cfg.n_text_ctx;
   c->max_prompt_alloc = c->cfg.n_text_ctx;
   TRY(dalloc(c, &c->st.cur_tok, B * 4)); TRY(dalloc(c, &c->st.step, 16)); TRY(dalloc(c, &c->st.n_sampled, B * 4));
@@ -338,12 +349,12 @@ template <typename T>
 void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
-      const char* v = getenv("TTASR_GEMM");  // force "v1" 128x128 two-stage, "v2" 256x128 three-stage, "v3" 256x256 four-stage
+      const int v = c->gemm_force;  // TTASR_GEMM: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage
       // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
       const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
-      if ((v ? v[1] == '3' : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->cur); return; }
-      if (!(v && v[1] == '1') && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->cur); return; }
+      if ((v ? v == 3 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->cur); return; }
+      if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->cur); return; }
       if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->cur); return; }
     }
   }
@@ -358,13 +369,6 @@ void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
     if (!c->force_basic && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
   }
   launch_gemm_basic<T>(g, c->cur);
-}
-
-// LayerNorm(x) followed by a decode GEMM (two launches: fusing LN into the GEMM was measured slower)
-template <typename T>
-void dec_ln_gemm(ttasr_ctx* c, const float* g_, const float* b_, int B, const GemmArgs& g, const void* Wsh) {
-  if (!(c->skip_mask & 1)) launch_layernorm<T>(c->dx, g_, b_, (T*)c->dh, B, c->d, c->cur);
-  dec_gemm<T>(c, g, Wsh);
 }
 
 template <typename T>
@@ -410,7 +414,7 @@ int run_encoder(ttasr_ctx* c, int B) {
     const EncLayerW& L = c->enc[l];
     launch_layernorm<T>(c->x, L.ln1g, L.ln1b, (T*)c->h, R, d, s);
     { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
-    if (sizeof(T) == 2 && !c->force_basic && getenv("TTASR_NO_FLASH") == nullptr)
+    if (sizeof(T) == 2 && !c->force_basic && !c->no_flash)
       launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
     else
       launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
@@ -428,9 +432,18 @@ int run_encoder(ttasr_ctx* c, int B) {
 
 // One decoder step for rows [row0, row0 + n) at position *st.step, enqueued on c->cur.
 // mode 0: through logits + select; 1: logits only (test API / beam search); 2: no logits (all rows forced by
-// the prompt), select just advances the forced token.
+// the prompt), select just advances the forced token.  `total_rows` = rows of the whole step (both half-batch chains):
+// the select launch that finishes last advances the position counter.
+//
+// bf16 launch plan per layer (the measured mode; no float atomics anywhere, every launch bit-reproducible):
+//   LN1 -> qkv GEMM (K-split, f32 slabs) -> self-attention (sums the q, k, v slabs) -> out-proj (K-split slabs) ->
+//   LN2 (x += bias + slabs, then normalise) -> q GEMM (K-split slabs) -> cross-attention (sums the q slabs) ->
+//   out-proj (slabs) -> LN3 (sums) -> fc1 + GELU (unsplit: the activation needs the full sum) -> fc2 (slabs) -> next LN1 (sums)
+// Splitting K spreads every weight matrix over >= 160 workgroups in pieces of <= 20-40 KB (a CU takes in only ~25 GB/s
+// of HBM-cold bytes).  LN1 of layer 0 creates the row from the token + position embedding itself.
+// The f32 parity mode runs the generic kernels: LayerNorm, gemm_basic with the residual epilogue in place.
 template <typename T>
-void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
+void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   const int d = c->d, ffn = c->ffn;
   hipStream_t s = c->cur;
   const size_t e = c->esz;
@@ -438,39 +451,90 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode) {
   float* dx = c->dx + (size_t)row0 * d;
   void *dh = tp(c->dh, d), *dqkv = tp(c->dqkv, 3 * d), *dq = tp(c->dq, d), *datt = tp(c->datt, d), *dmid = tp(c->dmid, ffn);
   float* logits = c->logits + (size_t)row0 * c->ldv;
-  auto ln_gemm = [&](const float* g_, const float* b_, const GemmArgs& g, const void* Wsh) {
-    if (!(c->skip_mask & 1)) launch_layernorm<T>(dx, g_, b_, (T*)dh, n, d, s);
+  const bool skinny = sizeof(T) == 2 && !c->force_basic;
+  // the two half-batch chains (TTASR_DUAL) run concurrently on GEMMs of different widths: each has its own slab region
+  float* slab_base = c->slab + (row0 ? (size_t)16 * c->maxB * 3 * d : 0);
+  // K slices per GEMM kind (0 out-proj, 1 q, 2 qkv, 3 fc2); attention consumers sum at most 4 slabs
+  auto slices = [&](int kind, int N, int K) {
+    if (!skinny) return 1;
+    int ks = gemm_skinny_ksplit(n, N, K, c->ks_want[kind]);
+    if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
+    return ks;
+  };
+  // what the next LayerNorm still has to add to the residual rows (K-split residual GEMM) or to create (embedding)
+  struct { const float* bias = nullptr; int n_slab = 0; bool embed = true; } pend;
+
+  // K-split GEMM into slabs [ks][maxB rows][N]; returns the slab descriptor for the consumer (n == 0: not split, `g` ran whole)
+  auto split_gemm = [&](const GemmArgs& g, const void* Wsh, const float* bias, int ks) -> SlabIn {
+    SlabIn si;
+    if constexpr (sizeof(T) == 2) {
+      if (ks > 1 && Wsh) {
+        GemmEpi ep; ep.ldc = g.N;
+        float* slab = slab_base;  // rows are local to this chain's region: [ks][maxB][N]
+        const int64_t stride = (int64_t)c->maxB * g.N;
+        if (launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, n, g.N, g.K, ep, s, ks, slab, stride)) {
+          si.slab = slab; si.bias = bias; si.n = ks; si.stride = stride; si.ld = g.N;
+        }
+      }
+    }
+    return si;
+  };
+  // x += W a + b
+  auto residual_gemm = [&](const void* A, const void* W, const void* Wsh, const float* bias, int K, int kind) {
+    if (c->skip_mask & 2) return;
+    GemmArgs g = lin_args<T>(A, W, n, d, K);
+    const SlabIn si = split_gemm(g, Wsh, bias, slices(kind, d, K));
+    if (si.n) { pend.bias = bias; pend.n_slab = si.n; return; }
+    g.epi.bias = bias; g.epi.residual = dx; g.epi.out_f32 = dx;
     dec_gemm<T>(c, g, Wsh);
   };
-  launch_embed<T>(c->st.cur_tok + row0, c->st.step, (const T*)c->emb, (const T*)c->dpos, dx, n, d, s);
+  auto ln = [&](const float* g_, const float* b_) {
+    if (c->skip_mask & 1) return;
+    LnPre pre;
+    pre.x_out = dx;
+    if (pend.embed) { pre.tok = c->st.cur_tok + row0; pre.step = c->st.step; pre.emb = c->emb; pre.pos = c->dpos; }
+    else if (pend.n_slab) { pre.bias = pend.bias; pre.slab = slab_base; pre.n_slab = pend.n_slab; pre.slab_stride = (int64_t)c->maxB * d; }
+    launch_layernorm_rows<T>(dx, g_, b_, (T*)dh, n, d, pre, s);
+    pend.bias = nullptr; pend.n_slab = 0; pend.embed = false;
+  };
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
-    { GemmArgs g = lin_args<T>(dh, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = dqkv; ln_gemm(L.ln1g, L.ln1b, g, L.wqkv_sh); }
+    ln(L.ln1g, L.ln1b);
+    SlabIn sqkv;
+    { GemmArgs g = lin_args<T>(dh, L.wqkv, n, 3 * d, d);
+      sqkv = split_gemm(g, L.wqkv_sh, L.bqkv, slices(2, 3 * d, d));
+      if (!sqkv.n) { g.epi.bias = L.bqkv; g.epi.out_t = dqkv; dec_gemm<T>(c, g, L.wqkv_sh); } }
     if (!(c->skip_mask & 4))
       launch_self_attn_decode<T>((const T*)dqkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
-                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s);
-    { GemmArgs g = lin_args<T>(datt, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.wo_sh); }
-    { GemmArgs g = lin_args<T>(dh, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = dq; ln_gemm(L.ln2g, L.ln2b, g, L.wqx_sh); }
+                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s, sqkv);
+    residual_gemm(datt, L.wo, L.wo_sh, L.bo, d, 0);
+    ln(L.ln2g, L.ln2b);
+    SlabIn sq;
+    { GemmArgs g = lin_args<T>(dh, L.wqx, n, d, d);
+      sq = split_gemm(g, L.wqx_sh, L.bqx, slices(1, d, d));
+      if (!sq.n) { g.epi.bias = L.bqx; g.epi.out_t = dq; dec_gemm<T>(c, g, L.wqx_sh); } }
     // cross-KV of clip (row / kv_div); a half-batch offset is only used with kv_div == 1
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
     if (!(c->skip_mask & 8))
       launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66);
-    { GemmArgs g = lin_args<T>(datt, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.wox_sh); }
-    { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; ln_gemm(L.ln3g, L.ln3b, g, L.w1_sh); }
-    { GemmArgs g = lin_args<T>(dmid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = dx; g.epi.out_f32 = dx; dec_gemm<T>(c, g, L.w2_sh); }
+                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq);
+    residual_gemm(datt, L.wox, L.wox_sh, L.box, d, 0);
+    ln(L.ln3g, L.ln3b);
+    { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; dec_gemm<T>(c, g, L.w1_sh); }
+    residual_gemm(dmid, L.w2, L.w2_sh, L.b2, ffn, 3);
   }
   if (mode != 2) {
+    ln(c->dlnf_g, c->dlnf_b);
     GemmArgs g = lin_args<T>(dh, c->emb, n, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
     g.epi.out_f32 = logits; g.epi.ldc = c->ldv;
-    ln_gemm(c->dlnf_g, c->dlnf_b, g, c->emb_sh);
+    dec_gemm<T>(c, g, c->emb_sh);
   }
   if (mode != 1 && !(c->skip_mask & 16)) {
     DecState st = c->st;  // row-offset view of the search state
     st.cur_tok += row0; st.n_sampled += row0; st.last_tok += row0; st.pen_tok += row0; st.last_ts += row0; st.done += row0;
     st.sum_logprob += row0; st.no_speech += row0; st.out_tokens += (size_t)row0 * c->rp.max_new;
     if (st.prompt) { st.prompt += (size_t)row0 * c->rp.max_prompt; st.prompt_len += row0; }
-    launch_select(logits, st, c->rp, n, nullptr, s);
+    launch_select(logits, st, c->rp, n, nullptr, s, c->st.step + 1, total_rows);
   }
 }
 
@@ -538,18 +602,19 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
   const bool dual = c->stream2 && c->kv_div == 1 && B >= c->dual_min_rows && B % 2 == 0;
   c->cur = c->stream;
   if (!dual) {
-    run_decode_rows<T>(c, 0, B, mode);
+    run_decode_rows<T>(c, 0, B, mode, B);
   } else {
     hipEventRecord(c->ev_fork, c->stream);
     hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-    run_decode_rows<T>(c, 0, B / 2, mode);
+    run_decode_rows<T>(c, 0, B / 2, mode, B);
     c->cur = c->stream2;
-    run_decode_rows<T>(c, B / 2, B / 2, mode);
+    run_decode_rows<T>(c, B / 2, B / 2, mode, B);
     c->cur = c->stream;
     hipEventRecord(c->ev_join, c->stream2);
     hipStreamWaitEvent(c->stream, c->ev_join, 0);
   }
-  launch_advance(c->st.step, c->stream);
+  // modes 0 and 2 end with select_kernel, whose last workgroup advances the position; mode 1 has no select
+  if (mode == 1 || (c->skip_mask & 16)) launch_advance(c->st.step, c->stream);
 }
 
 int step_graph(ttasr_ctx* c, int B, int mode) {
@@ -611,6 +676,16 @@ int upload_rules(ttasr_ctx* c, const ttasr_gen_opts* o, int max_prompt) {
 void drop_graphs(ttasr_ctx* c) {
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   c->graphs.clear();
+}
+// The rule scalars (RuleParams) are baked into the select launch of the mode 0 / 2 graphs only; the logits-only graphs
+// (mode 1: step API, beam search) never launch select_kernel and survive a change of rules - with
+// condition_on_previous_text the prompt geometry changes on nearly every window of a file.
+void drop_rule_graphs(ttasr_ctx* c) {
+  size_t k = 0;
+  for (auto& g : c->graphs) {
+    if (g.mode == 1) c->graphs[k++] = g; else hipGraphExecDestroy(g.exec);
+  }
+  c->graphs.resize(k);
 }
 
 int reset_search(ttasr_ctx* c, int B) {
@@ -687,7 +762,13 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
   c->no_prefill = getenv("TTASR_NO_PREFILL") != nullptr;
   c->no_xsplit = getenv("TTASR_NO_XSPLIT") != nullptr;
+#ifdef TTASR_EXPERIMENTS
   if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
+#endif
+  if (const char* v = getenv("TTASR_KS")) sscanf(v, "%d,%d,%d,%d", &c->ks_want[0], &c->ks_want[1], &c->ks_want[2], &c->ks_want[3]);
+  c->no_flash = getenv("TTASR_NO_FLASH") != nullptr;
+  if (const char* v = getenv("TTASR_GEMM")) c->gemm_force = (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0;
+  if (const char* v = getenv("TTASR_XATTN")) g_xattn_variant = atoi(v);
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
   if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));
@@ -727,10 +808,10 @@ void ttasr_destroy(ttasr_ctx* c) {
   delete c;
 }
 
-int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
-  return guarded(c, [&]() -> int {
-  if (!c) return TTASR_E_INVALID;
-  if (!name || !data || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
+// Shared by the host and device entry points: `src` is a DEVICE pointer to the tensor in its source layout (float32 or
+// bf16 bits); everything from here on - conv tap re-ordering, q pre-scaling, bf16 cast, MFMA-fragment packing - runs on
+// the device.
+static int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int src_bf16, const int64_t* dims, int32_t ndim) {
   if (std::string(name) == "proj_out.weight") return TTASR_OK;  // tied to embed_tokens
   auto it = c->slots.find(name);
   if (it == c->slots.end()) return fail(c, TTASR_E_WEIGHTS, "unknown tensor '%s'", name);
@@ -739,33 +820,45 @@ int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const i
   for (int i = 0; i < ndim; ++i) n *= dims[i];
   if (n != s.rows * s.cols) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': %lld elements, expected %lld", name, (long long)n,
                                         (long long)(s.rows * s.cols));
-  HIPCHK(c, hipSetDevice(c->device));
-  const float* src = data;
-  std::vector<float> tmp;
+  int64_t conv_in = 0;
   if (s.kind == 2) {  // [out][in][3] -> [out][3][in]: tap-major rows so conv == GEMM over a sliding window
     if (ndim != 3 || dims[2] != 3) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': expected [out][in][3]", name);
-    const int64_t O = dims[0], I = dims[1];
-    tmp.resize(n);
-    for (int64_t o = 0; o < O; ++o)
-      for (int64_t i = 0; i < I; ++i)
-        for (int k = 0; k < 3; ++k) tmp[(o * 3 + k) * I + i] = data[(o * I + i) * 3 + k];
-    src = tmp.data();
-  } else if (s.scale != 1.0f) {
-    tmp.resize(n);
-    for (int64_t i = 0; i < n; ++i) tmp[i] = data[i] * s.scale;
-    src = tmp.data();
+    conv_in = dims[1];
   }
-  if (s.kind == 1 || s.kind == 3 || !c->bf16) {
-    HIPCHK(c, hipMemcpyAsync(s.dst, src, n * 4, hipMemcpyHostToDevice, c->stream));
-  } else {
-    if ((size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
-    HIPCHK(c, hipMemcpyAsync(c->stage_f32, src, n * 4, hipMemcpyHostToDevice, c->stream));
+  const bool to_f32 = s.kind == 1 || s.kind == 3 || !c->bf16;
+  if (!to_f32 && (size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
+  float* f32_dst = to_f32 ? (float*)s.dst : c->stage_f32;
+  launch_prep_weight(src, src_bf16, f32_dst, n, conv_in, s.scale, c->stream);
+  if (!to_f32) {
     launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
     if (s.sh_base) launch_shuffle_cast(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // src/tmp are caller/stack owned
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffers are reused by the next tensor
+  HIPCHK(c, hipGetLastError());
   s.loaded = true;
   return TTASR_OK;
+}
+
+int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
+  return guarded(c, [&]() -> int {
+  if (!c) return TTASR_E_INVALID;
+  if (!name || !data || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= dims[i];
+  if (n < 0 || (size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': %lld elements exceed the staging buffer", name, (long long)n);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->stage_raw, data, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  return ingest_tensor(c, name, c->stage_raw, 0, dims, ndim);
+  });
+}
+
+int ttasr_load_tensor_device(ttasr_ctx* c, const char* name, const void* data_dev, int32_t dtype, const int64_t* dims, int32_t ndim) {
+  return guarded(c, [&]() -> int {
+  if (!c) return TTASR_E_INVALID;
+  if (!name || !data_dev || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16) return fail(c, TTASR_E_INVALID, "dtype must be TTASR_DTYPE_F32 or TTASR_DTYPE_BF16");
+  HIPCHK(c, hipSetDevice(c->device));
+  return ingest_tensor(c, name, data_dev, dtype == TTASR_DTYPE_BF16, dims, ndim);
   });
 }
 
@@ -934,7 +1027,7 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   RuleParams old = c->rp;
   TRY(upload_rules(c, o, max_prompt));
   c->rp.temperature = temperature; c->rp.seed = seed;
-  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_graphs(c);  // rule scalars are baked into the captured launches
+  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_rule_graphs(c);  // rule scalars are baked into the captured launches
   TRY(reset_search(c, R));
   hipStream_t s = c->stream;
   std::vector<int32_t> pr((size_t)R * max_prompt, 0), pl(R);
@@ -1050,7 +1143,7 @@ static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t
   auto sot_of = [&](int a) { return sots ? sots[a] : o->sot_index; };
   RuleParams old_rp = c->rp;
   TRY(upload_rules(c, o, max_prompt));
-  if (memcmp(&old_rp, &c->rp, sizeof old_rp) != 0) drop_graphs(c);
+  if (memcmp(&old_rp, &c->rp, sizeof old_rp) != 0) drop_rule_graphs(c);
   TRY(reset_search(c, R));
   c->st.prompt = nullptr; c->st.prompt_len = nullptr;
   c->B_dec = R;
@@ -1268,7 +1361,7 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   ttasr_gen_opts oo = *o;
   oo.max_new_tokens = std::max(1, std::min(oo.max_new_tokens, c->max_new_alloc));
   TRY(upload_rules(c, &oo, 1));
-  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_graphs(c);
+  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_rule_graphs(c);
   TRY(reset_search(c, n));
   std::vector<int32_t> ns(n), last(n, -1), pen(n, -1), lts(n, -1);
   for (int r = 0; r < n; ++r) {
@@ -1289,7 +1382,7 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   if (!c->rows_out) TRY(dalloc(c, &c->rows_out, (size_t)c->maxB * c->V * 4));
   DecState st = c->st; st.prompt = nullptr; st.prompt_len = nullptr;
   RuleParams rp = c->rp; rp.max_new = c->max_new_alloc;  // histories may be longer than opts.max_new_tokens
-  launch_select(c->logits, st, rp, n, c->rows_out, s);
+  launch_select(c->logits, st, rp, n, c->rows_out, s, nullptr, 0);
   HIPCHK(c, hipMemcpyAsync(out_rows, c->rows_out, (size_t)n * c->V * 4, hipMemcpyDeviceToHost, s));
   if (out_choice) HIPCHK(c, hipMemcpyAsync(out_choice, c->st.cur_tok, n * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1463,7 +1556,7 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       bytes = ((double)B * T_ * ffn + ffn * d) * e + 8.0 * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
       if (c->bf16) {
-        if (!c->force_basic && !getenv("TTASR_NO_FLASH")) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
+        if (!c->force_basic && !c->no_flash) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
         else launch_enc_attn_simple<bf16_t>((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
       } else launch_enc_attn_simple<float>((const float*)c->qkv, (float*)c->att, B, c->T, c->H, s);
       bytes = (double)B * T_ * 4.0 * d * e; flops = 4.0 * B * T_ * T_ * d;

@@ -99,6 +99,44 @@ template <> struct RowVec<bf16_t> {
   }
 };
 
+// One 16-byte chunk of a query / key / value row from the K-split partial tiles of the decode GEMM that produced it:
+// v = round_T(bias + slab[0] + ... + slab[n-1]) in slab order (bit-reproducible), i.e. exactly what the unsplit GEMM's
+// epilogue would have stored.  All loads are issued first (slab index clamped), n <= 4.
+template <typename T>
+__device__ __forceinline__ void load_row_slabs(const SlabIn& si, int64_t off, float (&v)[RowVec<T>::VEC]) {
+  constexpr int VEC = RowVec<T>::VEC, NF4 = VEC / 4, MAXS = 4;
+  float4 t[MAXS][NF4], bs[NF4];
+#pragma unroll
+  for (int c = 0; c < NF4; ++c) bs[c] = *(const float4*)(si.bias + (off % si.ld) + 4 * c);
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    const float* p = si.slab + (int64_t)min(s, si.n - 1) * si.stride + off;
+#pragma unroll
+    for (int c = 0; c < NF4; ++c) t[s][c] = *(const float4*)(p + 4 * c);
+  }
+#pragma unroll
+  for (int c = 0; c < NF4; ++c) {
+    float4 a = bs[c];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+      if (s < si.n) { a.x += t[s][c].x; a.y += t[s][c].y; a.z += t[s][c].z; a.w += t[s][c].w; }
+    v[4 * c] = to_f<T>(from_f<T>(a.x)); v[4 * c + 1] = to_f<T>(from_f<T>(a.y));
+    v[4 * c + 2] = to_f<T>(from_f<T>(a.z)); v[4 * c + 3] = to_f<T>(from_f<T>(a.w));
+  }
+}
+template <typename T> __device__ __forceinline__ void store_row(T* p, const float (&v)[RowVec<T>::VEC]);
+template <> __device__ __forceinline__ void store_row<float>(float* p, const float (&v)[4]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store_row<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 o;  // v holds exactly representable bf16 values
+  o.x = (__float_as_uint(v[0]) >> 16) | (__float_as_uint(v[1]) & 0xffff0000u);
+  o.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xffff0000u);
+  o.z = (__float_as_uint(v[4]) >> 16) | (__float_as_uint(v[5]) & 0xffff0000u);
+  o.w = (__float_as_uint(v[6]) >> 16) | (__float_as_uint(v[7]) & 0xffff0000u);
+  *(uint4*)p = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 // decoder self-attention with paged KV cache.
 // Pool layout per layer: [page][2 (K,V)][H][PAGE=16 tokens][64]; page_table[b][i] = page of tokens
@@ -107,6 +145,8 @@ template <> struct RowVec<bf16_t> {
 // over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
+int g_xattn_variant = 1;  // TTASR_XATTN (experiments); default 1 = nontemporal K/V loads
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 
 // Single pass, one memory round trip for pos <= 32*UNROLL cached keys: every lane keeps an online-softmax
 // state (m, l, acc[VEC]) for its row slot, K and V rows of an iteration are requested together, and the
@@ -122,7 +162,7 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
                                                                const int32_t* __restrict__ page_table, int pages_per_seq,
                                                                int identity_pages, int row0,
                                                                const int32_t* __restrict__ step, T* __restrict__ out, int H,
-                                                               int npos) {
+                                                               int npos, SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
   __shared__ float part[4][64];
@@ -132,9 +172,24 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float q[VEC], kn[VEC], vn[VEC];
-  RowVec<T>::load(qp + sub * VEC, q);
-  RowVec<T>::load(qp + d + sub * VEC, kn);
-  RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
+  if (MODE == 0 && sq.n > 0) {  // qkv GEMM was K-split: complete q, k, v from its partial tiles
+    // waves 0 / 1 / 2 sum q / k / v (their first LPR lanes, one 16-byte chunk each) and share them through LDS:
+    // 24 lanes issue the slab loads instead of all 256
+    __shared__ float qkv_s[3][64];
+    if (wave < 3 && rin == 0) {
+      float t[VEC];
+      load_row_slabs<T>(sq, (int64_t)b * 3 * d + wave * d + h * 64 + sub * VEC, t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) qkv_s[wave][sub * VEC + j] = t[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { q[j] = qkv_s[0][sub * VEC + j]; kn[j] = qkv_s[1][sub * VEC + j]; vn[j] = qkv_s[2][sub * VEC + j]; }
+  } else {
+    RowVec<T>::load(qp + sub * VEC, q);
+    RowVec<T>::load(qp + d + sub * VEC, kn);
+    RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
+  }
   // global row: qkv / out are already offset to the half-batch, the KV pages are not
   const int bg = MODE == 0 ? b + row0 : b / npos;
   const int32_t* pt = page_table + bg * pages_per_seq;
@@ -143,8 +198,8 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
     const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
     T* vdst = pool + ((((int64_t)page * 2 + 1) * H + h) * PAGE + (pos % PAGE)) * 64;
-    *(uint4*)(kdst + sub * VEC) = *(const uint4*)(qp + d + sub * VEC);
-    *(uint4*)(vdst + sub * VEC) = *(const uint4*)(qp + 2 * d + sub * VEC);
+    store_row<T>(kdst + sub * VEC, kn);
+    store_row<T>(vdst + sub * VEC, vn);
   }
   if (MODE == 1) return;
   // this lane's slot: rows t = (it*4 + wave)*RPI + rin of the cached keys 0..pos-1
@@ -220,19 +275,19 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
 }
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
-                             int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s) {
+                             int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s, SlabIn sq) {
   // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
   hipLaunchKernelGGL((self_attn_decode_kernel<T, 0>), dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, identity_pages, row0, step, out, H, 1);
+                     pages_per_seq, identity_pages, row0, step, out, H, 1, sq);
 }
 // prompt prefill: rows = n_seq * npos, row-major [sequence][position]; positions 0..npos-1 of every sequence
 template <typename T>
 void launch_self_attn_prefill(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                               int identity_pages, T* out, int n_seq, int npos, int H, hipStream_t s) {
   hipLaunchKernelGGL((self_attn_decode_kernel<T, 1>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
-                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos);
+                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{});
   hipLaunchKernelGGL((self_attn_decode_kernel<T, 2>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
-                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos);
+                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{});
 }
 template void launch_self_attn_prefill<float>(const float*, float*, const int32_t*, int, int64_t, int, float*, int, int, int, hipStream_t);
 template void launch_self_attn_prefill<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, bf16_t*, int, int, int,
@@ -256,9 +311,9 @@ void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_lay
 template void launch_copy_pages<float>(float*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_copy_pages<bf16_t>(bf16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, int, const int32_t*, float*,
-                                             int, int, hipStream_t);
+                                             int, int, hipStream_t, SlabIn);
 template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
-                                              bf16_t*, int, int, hipStream_t);
+                                              bf16_t*, int, int, hipStream_t, SlabIn);
 
 // ------------------------------------------------------------------------------------------------
 // decoder cross-attention.  K, V: [B][H][Tk][64] (head-major, written by the cross-KV GEMM epilogue), so
@@ -270,38 +325,51 @@ template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int3
 // Algorithmic bytes per launch: B*H*2*Tk*64*sizeof(T) (+ q, out): 245.8 MB per clip-step-layer... see DESIGN.md.
 // ------------------------------------------------------------------------------------------------
 // PROBS = true is the alignment (word-timestamp) pass: heads listed in `sel` (sel[h] >= 0) also write their softmax
-// row to probs[sel[h]][b][0..Tk).  The PROBS = false instantiation is the decode-step kernel, unchanged.
-template <typename T, bool PROBS>
-__global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
-                                                                const T* __restrict__ V, T* __restrict__ out, int H, int Tk,
-                                                                int kv_div, const int* __restrict__ sel,
-                                                                float* __restrict__ probs) {
+// row to probs[sel[h]][b][0..Tk).  The PROBS = false instantiation is the decode-step kernel.
+// NWV waves per workgroup, UNROLL rows in flight per lane, NT = nontemporal K/V loads (the 7.9 GB of cross-KV a step
+// streams is read exactly once per step and can never stay in a cache: variants measured in DESIGN.md).
+template <typename T, bool NT> __device__ __forceinline__ void load_row(const T* p, float (&v)[RowVec<T>::VEC]) {
+  if constexpr (NT && sizeof(T) == 2) {
+    const u32x4_t t = __builtin_nontemporal_load((const u32x4_t*)p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  } else {
+    RowVec<T>::load(p, v);
+  }
+}
+template <typename T, bool PROBS, int NWV, int UNROLL, bool NT>
+__global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
+                                                                     const T* __restrict__ V, T* __restrict__ out, int H, int Tk,
+                                                                     int kv_div, const int* __restrict__ sel,
+                                                                     float* __restrict__ probs, SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
-  constexpr int UNROLL = 8;
-  extern __shared__ float sc[];  // [Tk] scores, then [4][64] partial outputs, [8] reductions
+  extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
   const int sub = lane % LPR, rin = lane / LPR;
-  float* part = sc + Tk;        // [4][64]
-  float* red = part + 4 * 64;   // [8]
+  float* part = sc + Tk;          // [NWV][64]
+  float* red = part + NWV * 64;   // [2 * NWV]
   float qv[VEC];
-  RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  if (!PROBS && sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);  // q GEMM was K-split
+  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
   const int bk = b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
   const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64;
   const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64;
   float mloc = -1e30f;
-  // rows handled by this wave: t = (it*4 + wave)*RPI + rin
-  const int n_it = (Tk + 4 * RPI - 1) / (4 * RPI);
+  // rows handled by this wave: t = (it*NWV + wave)*RPI + rin
+  const int n_it = (Tk + NWV * RPI - 1) / (NWV * RPI);
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
     float kv[UNROLL][VEC];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      RowVec<T>::load(Kp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
+      int t = ((it0 + u) * NWV + wave) * RPI + rin;
+      load_row<T, NT>(Kp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      int t = ((it0 + u) * NWV + wave) * RPI + rin;
       float s = 0.f;
       if (t < Tk) {
 #pragma unroll
@@ -318,23 +386,29 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
   mloc = wave_max(mloc);
   if (lane == 0) red[wave] = mloc;
   __syncthreads();
-  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float mx = red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) mx = fmaxf(mx, red[w]);
   float lsum = 0.f;
-  for (int t = tid; t < Tk; t += 256) {
+  for (int t = tid; t < Tk; t += NWV * 64) {
     float p = __expf(sc[t] - mx);
     sc[t] = p;
     lsum += p;
   }
   lsum = wave_sum(lsum);
-  if (lane == 0) red[4 + wave] = lsum;
+  if (lane == 0) red[NWV + wave] = lsum;
   __syncthreads();
-  const float denom = (red[4] + red[5]) + (red[6] + red[7]);
+  float denom;
+  if constexpr (NWV == 4) denom = (red[4] + red[5]) + (red[6] + red[7]);
+  else { denom = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) denom += red[NWV + w]; }
   if constexpr (PROBS) {
     const int si = sel[h];
     if (si >= 0) {
       float* dst = probs + ((int64_t)si * gridDim.y + b) * Tk;
       const float inv = 1.f / denom;
-      for (int t = tid; t < Tk; t += 256) dst[t] = sc[t] * inv;
+      for (int t = tid; t < Tk; t += NWV * 64) dst[t] = sc[t] * inv;
     }
   }
   float acc[VEC];
@@ -344,12 +418,12 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
     float vv[UNROLL][VEC];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      RowVec<T>::load(Vp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, vv[u]);
+      int t = ((it0 + u) * NWV + wave) * RPI + rin;
+      load_row<T, NT>(Vp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, vv[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      int t = ((it0 + u) * NWV + wave) * RPI + rin;
       if (t < Tk) {
         float p = sc[t];
 #pragma unroll
@@ -368,7 +442,11 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
   }
   __syncthreads();
   if (tid < 64) {
-    float v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    float v;
+    if constexpr (NWV == 4) v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    else { v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) v += part[w * 64 + tid]; }
     out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
   }
 }
@@ -381,7 +459,7 @@ __global__ __launch_bounds__(256) void cross_attn_decode_kernel(const T* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restrict__ q, const T* __restrict__ K,
                                                                const T* __restrict__ V, int H, int Tk, int kv_div, int chunk,
-                                                               float* __restrict__ ws) {
+                                                               float* __restrict__ ws, SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = 8;
   extern __shared__ float sc[];  // [chunk] scores, then [4][64] partial outputs, [8] reductions
@@ -392,7 +470,8 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
   float* part = sc + chunk;
   float* red = part + 4 * 64;
   float qv[VEC];
-  RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  if (sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);
+  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
   const int bk = b / kv_div;
   const int t0 = z * chunk, n = min(chunk, Tk - t0);  // this slice: frames t0 .. t0+n-1 (n >= 1 by construction)
   const T* Kp = K + (((int64_t)bk * H + h) * Tk + t0) * 64;
@@ -506,31 +585,47 @@ int cross_attn_splits(int B, int H, int Tk) {
 
 template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
-                              float* split_ws) {
+                              float* split_ws, SlabIn sq) {
   const int S = split_ws ? cross_attn_splits(B, H, Tk) : 1;
   if (S > 1) {
     int chunk = ((Tk + S - 1) / S + 31) / 32 * 32;
     const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty
     size_t lds = sizeof(float) * (chunk + 4 * 64 + 8);
-    hipLaunchKernelGGL(cross_attn_split_kernel<T>, dim3(H, B, S2), dim3(256), lds, s, q, K, V, H, Tk, kv_div, chunk, split_ws);
+    hipLaunchKernelGGL(cross_attn_split_kernel<T>, dim3(H, B, S2), dim3(256), lds, s, q, K, V, H, Tk, kv_div, chunk, split_ws, sq);
     hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
     return;
   }
-  size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, false>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div,
-                     (const int*)nullptr, (float*)nullptr);
+  // g_xattn_variant (TTASR_XATTN, A/B testing): bit 0 nontemporal K/V loads, bit 1 16 rows in flight per lane, bit 2 8 waves
+  const int var = g_xattn_variant;
+  const int nwv = (var & 4) ? 8 : 4;
+  size_t lds = sizeof(float) * (Tk + nwv * 64 + 2 * nwv);
+#define TTASR_XA(NWV_, UN_, NT_)                                                                                          \
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
+                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq)
+  switch (var & 7) {
+    case 1: TTASR_XA(4, 8, true); break;
+    case 2: TTASR_XA(4, 16, false); break;
+    case 3: TTASR_XA(4, 16, true); break;
+    case 4: TTASR_XA(8, 8, false); break;
+    case 5: TTASR_XA(8, 8, true); break;
+    case 6: TTASR_XA(8, 4, false); break;
+    case 7: TTASR_XA(8, 4, true); break;
+    default: TTASR_XA(4, 8, false); break;
+  }
+#undef TTASR_XA
 }
 // alignment pass: rows = token positions of one sequence; heads with sel[h] >= 0 dump their attention rows
 template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel, float* probs,
                              hipStream_t s) {
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs);
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{});
 }
 template void launch_cross_attn_probs<float>(const float*, const float*, const float*, float*, int, int, int, const int*, float*,
                                              hipStream_t);
 template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, const int*, float*,
                                               hipStream_t);
-template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*);
+template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*,
+                                              SlabIn);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
-                                               float*);
+                                               float*, SlabIn);

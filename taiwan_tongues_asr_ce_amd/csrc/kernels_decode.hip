@@ -1,26 +1,11 @@
-// Decoder glue kernels: token+position embedding, and the fused logits-processor / greedy-selection
+// Decoder glue kernels: prompt-prefill embedding (the per-step embedding is created by the first LayerNorm of the
+// step, kernels_misc.hip layernorm_rows_kernel), and the fused logits-processor / greedy-selection
 // kernel.  The selection kernel restates CTranslate2's Whisper logits processors + greedy search
 // (un-vendored) == HF generation/logits_process.py:1816 (begin-suppress), :1869 (suppress),
 // :2000-2047 (timestamp rules), generation_whisper.py:1774-1812 (stack order); tie-breaking = first
 // maximum, as torch.argmax.  All search state lives in device memory so a whole decode step can be
 // replayed as a hipGraph with no host round trip.
 #include "common.hpp"
-
-template <typename T>
-__global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ step,
-                                                    const T* __restrict__ emb, const T* __restrict__ pos, float* __restrict__ x,
-                                                    int d) {
-  const int b = blockIdx.x, p = *step;
-  const T* e = emb + (int64_t)tok[b] * d;
-  const T* pe = pos + (int64_t)p * d;
-  for (int i = threadIdx.x; i < d; i += 256) x[(int64_t)b * d + i] = to_f<T>(e[i]) + to_f<T>(pe[i]);
-}
-template <typename T>
-void launch_embed(const int32_t* tok, const int32_t* step, const T* emb, const T* pos, float* x, int B, int d, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, s, tok, step, emb, pos, x, d);
-}
-template void launch_embed<float>(const int32_t*, const int32_t*, const float*, const float*, float*, int, int, hipStream_t);
-template void launch_embed<bf16_t>(const int32_t*, const int32_t*, const bf16_t*, const bf16_t*, float*, int, int, hipStream_t);
 
 // prompt prefill: row b = position (b % npos) of sequence (b / npos); token from the uploaded prompt table
 template <typename T>
@@ -114,8 +99,13 @@ __device__ __forceinline__ float gumbel_noise(uint32_t key, int i) {
 // One workgroup (1024 threads) per row.  Pass 1: masked max/argmax of the text and timestamp ranges.
 // Pass 2: sum of exp over both ranges (f32).  Then the "timestamp mass > best text token" rule, the
 // choice, its log-probability, and the state update.  Reads the V-float row twice from L2.
+// The position counter: every workgroup reads *st.step when it starts; the one that draws the last ticket (all
+// `total_rows` workgroups of the step, over both half-batch launches, have then read it) advances it.
+__device__ __forceinline__ void step_ticket(int32_t* ticket, int total_rows, int32_t* step) {
+  if (ticket && atomicAdd(ticket, 1) == total_rows - 1) { *ticket = 0; *step += 1; }
+}
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ logits, DecState st, RuleParams p,
-                                                      float* __restrict__ out_rows) {
+                                                      float* __restrict__ out_rows, int32_t* ticket, int total_rows) {
   __shared__ ArgMax s_am[2][16];
   __shared__ float s_sum[3][16];
   __shared__ float s_b[8];
@@ -127,7 +117,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   const bool forced = st.prompt && (step + 1 < plen);
   const bool want_ns = p.no_speech >= 0 && step == p.sot_index && st.no_speech;
   if (forced && !want_ns && !out_rows) {
-    if (tid == 0) st.cur_tok[b] = st.prompt[b * p.max_prompt + step + 1];
+    if (tid == 0) { st.cur_tok[b] = st.prompt[b * p.max_prompt + step + 1]; step_ticket(ticket, total_rows, st.step); }
     return;
   }
   RowRule r;
@@ -231,6 +221,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
     if (choice >= tb && p.timestamps) st.last_ts[b] = choice;
     if (choice == p.eot || r.n + 1 >= p.max_new) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
   }
+  if (tid == 0) step_ticket(ticket, total_rows, st.step);
   if (out_rows) {  // known-answer hook: the forced-timestamp branch also masks the text range
     __syncthreads();
     if (s_i[2])
@@ -238,8 +229,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   }
 }
 
-void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows, hipStream_t s) {
-  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, s, logits, st, rp, out_rows);
+void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows, hipStream_t s, int32_t* ticket,
+                   int total_rows) {
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(1024), 0, s, logits, st, rp, out_rows, ticket, total_rows);
 }
 
 // log p(target | row) from raw logits (alignment pass: probability of each text token), one workgroup per row

@@ -205,10 +205,120 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, T* 
   else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, gamma, beta, out, rows, d);
   else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, gamma, beta, out, rows, d);
 }
+// ------------------------------------------------------------------------------------------------
+// Decode-step LayerNorm (rows <= 128): one WORKGROUP per row, one float4 per thread, so the few rows of a decode
+// step spread over as many CUs as there are rows and every thread has a single round trip of (4 + n_slab)
+// independent loads.  The row is first completed from the K-split partial tiles of the residual GEMM before it:
+//     x_new = x + bias + slab[0] + slab[1] + ... + slab[n_slab-1]        (fixed order: bit-reproducible)
+// written back to the f32 residual stream, then normalised to T.  `tok != nullptr` instead CREATES the row as the
+// token + position embedding of this step (first LayerNorm of the decoder: replaces the embed launch).
+// MAXS = compile-time bound on n_slab: the loads of all slabs are issued unconditionally (index clamped), nothing
+// branches around a load.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MAXS, bool EMBED>
+__global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ out, int d,
+                                                             LnPre pre) {
+  __shared__ float red[2][8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const int nv = d >> 2, i = min(tid, nv - 1);
+  const bool live = tid < nv;
+  float4 v;
+  const float4 gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
+  if constexpr (EMBED) {
+    const T* er = (const T*)pre.emb + (int64_t)pre.tok[row] * d;
+    const T* pr = (const T*)pre.pos + (int64_t)(*pre.step) * d;
+    if constexpr (sizeof(T) == 4) {
+      const float4 a = ((const float4*)er)[i], b = ((const float4*)pr)[i];
+      v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    } else {
+      const uint2 a = ((const uint2*)er)[i], b = ((const uint2*)pr)[i];
+      v = make_float4(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16),
+                      __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u),
+                      __uint_as_float(a.y << 16) + __uint_as_float(b.y << 16),
+                      __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
+    }
+  } else {
+    v = ((const float4*)(x + (int64_t)row * d))[i];
+    if constexpr (MAXS > 0) {
+      const float4 bs = ((const float4*)pre.bias)[i];
+      float4 sl[MAXS];
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s)
+        sl[s] = ((const float4*)(pre.slab + (int64_t)min(s, pre.n_slab - 1) * pre.slab_stride + (int64_t)row * d))[i];
+      v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s)
+        if (s < pre.n_slab) { v.x += sl[s].x; v.y += sl[s].y; v.z += sl[s].z; v.w += sl[s].w; }
+    }
+  }
+  if (live && (EMBED || MAXS > 0)) ((float4*)(pre.x_out + (int64_t)row * d))[i] = v;
+  float s1 = live ? (v.x + v.y) + (v.z + v.w) : 0.f;
+  s1 = wave_sum(s1);
+  if (lane == 0) red[0][wave] = s1;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < nwave; ++w) tot += red[0][w];
+  const float mean = tot / d;
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+  float s2 = live ? (a * a + b * b) + (c * c + e * e) : 0.f;
+  s2 = wave_sum(s2);
+  if (lane == 0) red[1][wave] = s2;
+  __syncthreads();
+  float tot2 = 0.f;
+  for (int w = 0; w < nwave; ++w) tot2 += red[1][w];
+  const float rstd = rsqrtf(tot2 / d + 1e-5f);
+  if (!live) return;
+  const float r0 = a * rstd * gm.x + bt.x, r1 = b * rstd * gm.y + bt.y, r2 = c * rstd * gm.z + bt.z, r3 = e * rstd * gm.w + bt.w;
+  T* o = out + (int64_t)row * d;
+  if constexpr (sizeof(T) == 4) {
+    ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
+  } else {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 lo = {(__bf16)r0, (__bf16)r1}, hi = {(__bf16)r2, (__bf16)r3};
+    uint2 p;
+    p.x = __builtin_bit_cast(uint32_t, lo);
+    p.y = __builtin_bit_cast(uint32_t, hi);
+    ((uint2*)o)[i] = p;
+  }
+}
+template <typename T>
+void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const LnPre& pre,
+                           hipStream_t s) {
+  const int threads = ((d / 4) + 63) / 64 * 64;  // d <= 1280 (ttasr_create) -> <= 320 threads
+  dim3 grid(rows), block(threads);
+  if (pre.tok) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, true>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab == 0) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab <= 2) hipLaunchKernelGGL((layernorm_rows_kernel<T, 2, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab <= 4) hipLaunchKernelGGL((layernorm_rows_kernel<T, 4, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab <= 8) hipLaunchKernelGGL((layernorm_rows_kernel<T, 8, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+}
+template void launch_layernorm_rows<float>(const float*, const float*, const float*, float*, int, int, const LnPre&, hipStream_t);
+template void launch_layernorm_rows<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, const LnPre&, hipStream_t);
 template void launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
+// Weight intake: source layout (f32 or bf16 bits, as the checkpoint / the RCCL broadcast delivers it) -> f32 in the
+// engine's layout.  conv_in > 0: [out][in][3] -> [out][3][in]; `scale` folds the q pre-scaling (1/8: exact in bf16 too).
+__global__ void prep_weight_kernel(const void* __restrict__ src, int src_bf16, float* __restrict__ dst, int64_t n, int64_t conv_in,
+                                   float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t j = i;
+    if (conv_in > 0) {  // i = (o*3 + k)*I + c  <-  (o*I + c)*3 + k
+      const int64_t c = i % conv_in, ok = i / conv_in, k = ok % 3, o = ok / 3;
+      j = (o * conv_in + c) * 3 + k;
+    }
+    const float v = src_bf16 ? bf2f(((const bf16_t*)src)[j]) : ((const float*)src)[j];
+    dst[i] = v * scale;
+  }
+}
+void launch_prep_weight(const void* src, int src_bf16, float* dst, int64_t n, int64_t conv_in, float scale, hipStream_t s) {
+  int64_t nb = (n + 255) / 256; int blocks = (int)(nb < 8192 ? nb : 8192);
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, src, src_bf16, dst, n, conv_in, scale);
+}
+
 template <typename T>
 __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

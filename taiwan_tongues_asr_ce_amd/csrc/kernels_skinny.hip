@@ -14,8 +14,16 @@
 //   5.0 us, at the 2:1 ratio of the 16x16x32 form 7.1 us; nontemporal weight loads +1.8 us.
 // Hence: 32x32x16 (1 KiB of x per 1 KiB of W), plain loads, and every load of the kernel (fragments, bias,
 // residual) issued before the first use: one memory round trip per kernel (each extra one costs ~1.5 us in
-// the decode chain).  NW waves split K inside the workgroup (LDS reduce); residual GEMMs additionally split K
-// across workgroups and add their partials to the f32 residual stream with float atomics.
+// the decode chain).  NW waves split K inside the workgroup (LDS reduce, fixed order).
+//
+// What bounds these kernels (round 2, rocprofv3 timeline of the real chain): a CU takes in only ~25 GB/s of HBM-cold
+// bytes (its outstanding-miss queue over ~1 us of latency), and after every kernel boundary the activation rows come from
+// the Infinity Cache, not L2.  So a GEMM wants its weights spread over ALL 256 CUs in pieces of <= ~40 KB: every decode GEMM
+// whose consumer can sum partial results splits K across `ksplit` workgroups, each writing its partial tile to f32 slab
+// `ks` ([ksplit][rows][ldc]) - no float atomics anywhere, so every result is bit-reproducible.  The consumers add the
+// slabs in slab order: the LayerNorm after a residual GEMM (layernorm_rows_kernel: x + bias + slab[0] + ...), the
+// self-attention kernel (q, k, v) and the cross-attention kernel (q).  fc1 (GELU needs the full sum) and the vocabulary
+// GEMM stay unsplit.
 #include "common.hpp"
 #include <cstdlib>
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -50,10 +58,12 @@ void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, in
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
 // which is what amortises the per-step latency when more clips are in flight).
-template <int NW, int RB>
+template <int NW, int RB, int U>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
-                                                              int B, int N, int K, int ksplit, GemmEpi e) {
-  constexpr int U = RB == 1 ? 10 : (RB == 2 ? 8 : 5);  // k-steps in flight per wave (register budget: U * (1 + RB) * 4)
+                                                              int B, int N, int K, int ksplit, GemmEpi e,
+                                                              float* __restrict__ slab, int64_t slab_stride) {
+  // U = k-steps in flight per wave (register budget: U * (1 + RB) * 4); the launcher picks the smallest instantiated
+  // U >= steps so that no load is issued twice
   __shared__ __attribute__((aligned(16))) float red[NW][RB][32 * 32];  // [wave][row group][b*32 + n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
 #pragma unroll
   for (int g = 0; g < RB; ++g) eres[g] = ebias;
   if (tid < 256 && en + 3 < N) {
-    if (e.bias && (ksplit == 1 || ks == 0)) ebias = *(const float4*)(e.bias + en);
+    if (e.bias && ksplit == 1) ebias = *(const float4*)(e.bias + en);
     if (e.residual && ksplit == 1) {
 #pragma unroll
       for (int g = 0; g < RB; ++g) eres[g] = *(const float4*)(e.residual + (int64_t)min(g * 32 + (tid >> 3), B - 1) * e.ldc + en);
@@ -121,6 +131,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
     float vv[4] = {v.x, v.y, v.z, v.w};
     const float rr[4] = {eres[g].x, eres[g].y, eres[g].z, eres[g].w};
     const int64_t idx0 = (int64_t)b * e.ldc + en;
+    if (en + 3 < N && ksplit > 1) {  // K-split partial: one 16-byte store into this slice's slab
+      *(float4*)(slab + (int64_t)ks * slab_stride + idx0) = v;
+      continue;
+    }
     if (en + 3 < N && ksplit == 1) {  // full 4-column cell: vector stores
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
       if (n < N) {
         const int64_t idx = idx0 + j;
         if (ksplit > 1) {
-          atomicAdd(e.out_f32 + idx, vv[j]);  // accumulate into the f32 residual stream
+          slab[(int64_t)ks * slab_stride + idx] = vv[j];  // partial tile of K-slice ks (bias / residual: the following LayerNorm)
         } else {
           float o = vv[j];
           if (e.bias) o += e.bias[n];  // ragged tail block (vocabulary): operands were not prefetched
@@ -156,41 +170,71 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   }
 }
 
-// Chooses (waves per workgroup, K split across workgroups) so that each wave owns <= 10 k-steps (one round
-// trip) and the grid has a few hundred workgroups.  Only residual GEMMs (x += W h + b) may split K across
-// workgroups.  Returns false when the shape does not fit (caller falls back to gemm_basic).
-bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s) {
+// K slices a split decode GEMM is cut into (1 = unsplit).  `want` = requested slice count (0 = automatic: weights in
+// pieces of <= ~20 KB per workgroup, a few hundred workgroups); the result divides the k-steps evenly over 4 waves.
+int gemm_skinny_ksplit(int B, int N, int K, int want) {
+  if (B < 1 || B > 128 || K % 64 != 0) return 1;
+  const int rb = (B + 31) / 32, n_blocks = (N + 31) / 32, ks_per = K / 16;
+  const int per4 = ks_per / 4;  // k-steps per wave of a 4-wave workgroup when unsplit
+  if (ks_per % 4 != 0) return 1;
+  int best = 1;
+  if (want > 0) {  // largest divisor of per4 that is <= want
+    for (int s = 1; s <= want && s <= 16; ++s) if (per4 % s == 0) best = s;
+    return best;
+  }
+  const int u_max = rb == 1 ? 10 : (rb == 2 ? 8 : 5);
+  for (int s = 1; s <= 16; ++s) {
+    if (per4 % s != 0) continue;
+    best = s;
+    const int steps = per4 / s;
+    // one round trip per wave, and either every CU busy or <= 5 KiB of weights per wave on >= 160 workgroups
+    if (steps <= u_max && ((steps <= 10 && n_blocks * s >= 256) || (steps <= 5 && n_blocks * s >= 160))) break;
+  }
+  return best;
+}
+
+// Chooses the waves per workgroup so that each wave owns <= 10 k-steps (one round trip) where the shape allows.
+// ksplit > 1 (gemm_skinny_ksplit): partial tiles go to `slab`, bias / activation / residual are the consumer's job.
+// Returns false when the shape does not fit (caller falls back to gemm_basic).
+bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit,
+                        float* slab, int64_t slab_stride) {
   if (B < 1 || B > 128 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
   const int rb = (B + 31) / 32;  // 32-row groups sharing one weight stream
   const int n_blocks = (N + 31) / 32;
   const int ks_per = K / 16;
-  const bool can_split = e.out_f32 && e.residual == e.out_f32 && e.act == 0 && !e.out_t;
-  const int u = rb == 1 ? 10 : (rb == 2 ? 8 : 5);  // k-steps a wave keeps in flight (kernel's U)
-  int nw = 4, ksplit = 1;
-  if (can_split) {
-    // 8 waves first (LDS reduce is cheaper than contended atomics), then split K across workgroups until a
-    // wave owns <= 10 k-steps; keep at least ~160 workgroups when the shape allows
-    if (ks_per >= 160 && ks_per % 8 == 0) nw = 8;  // long K (fc2): fewer, fatter workgroups = half the atomics
-    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > u) ksplit *= 2;
-    while (ks_per % (nw * ksplit * 2) == 0 && ks_per / (nw * ksplit) > 5 && n_blocks * ksplit < 160) ksplit *= 2;
+  const int u_max = rb == 1 ? 10 : (rb == 2 ? 8 : 5);  // k-steps a wave can keep in flight (registers)
+  int nw = 4;
+  if (ksplit > 1) {
+    if (!slab || e.act != 0) return false;
   } else {
+    ksplit = 1;
     const int nw_max = rb == 1 ? 16 : 8;  // 16 waves leave 128 VGPRs per lane: only the single row group fits
-    while (nw < nw_max && ks_per % (nw * 2) == 0 && ks_per / nw > u) nw *= 2;
+    while (nw < nw_max && ks_per % (nw * 2) == 0 && ks_per / nw > u_max) nw *= 2;
     if (nw < 8 && ks_per % 8 == 0 && ks_per / 8 >= 5 && n_blocks < 256) nw = 8;
   }
-  if (const char* f = getenv("TTASR_SKINNY_NW")) { if (!can_split && rb == 1) nw = atoi(f); }  // tuning experiments
   if (ks_per % (nw * ksplit) != 0) return false;
+  const int steps = ks_per / (nw * ksplit);
   dim3 grid(n_blocks, ksplit);
-#define TTASR_SKINNY(NW_, RB_) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e)
+#define TTASR_SKINNY(NW_, RB_, U_) \
+  hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride)
+#define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
+  do {                                                                             \
+    if (steps <= 2 && UMAX_ >= 2) TTASR_SKINNY(NW_, RB_, 2);                       \
+    else if (steps <= 4 && UMAX_ >= 4) TTASR_SKINNY(NW_, RB_, 4);                  \
+    else if (steps <= 5 || UMAX_ == 5) TTASR_SKINNY(NW_, RB_, 5);                  \
+    else if (steps <= 8 || UMAX_ == 8) TTASR_SKINNY(NW_, RB_, 8);                  \
+    else TTASR_SKINNY(NW_, RB_, 10);                                               \
+  } while (0)
   if (rb == 1) {
-    if (nw == 16) TTASR_SKINNY(16, 1); else if (nw == 8) TTASR_SKINNY(8, 1); else TTASR_SKINNY(4, 1);
+    if (nw == 16) TTASR_SKINNY_U(16, 1, 10); else if (nw == 8) TTASR_SKINNY_U(8, 1, 10); else TTASR_SKINNY_U(4, 1, 10);
   } else if (rb == 2) {
-    if (nw == 8) TTASR_SKINNY(8, 2); else TTASR_SKINNY(4, 2);
+    if (nw == 8) TTASR_SKINNY_U(8, 2, 8); else TTASR_SKINNY_U(4, 2, 8);
   } else if (rb == 3) {
-    if (nw == 8) TTASR_SKINNY(8, 3); else TTASR_SKINNY(4, 3);
+    if (nw == 8) TTASR_SKINNY_U(8, 3, 5); else TTASR_SKINNY_U(4, 3, 5);
   } else {
-    if (nw == 8) TTASR_SKINNY(8, 4); else TTASR_SKINNY(4, 4);
+    if (nw == 8) TTASR_SKINNY_U(8, 4, 5); else TTASR_SKINNY_U(4, 4, 5);
   }
+#undef TTASR_SKINNY_U
 #undef TTASR_SKINNY
   return true;
 }

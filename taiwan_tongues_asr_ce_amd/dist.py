@@ -39,47 +39,76 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _is_matrix(name: str, shape) -> bool:
+    """Tensors the bf16 engine stores in bf16 (every weight matrix except the f32 encoder position table)."""
+    return len(shape) >= 2 and name != "model.encoder.embed_positions.weight"
+
+
 def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, np.ndarray]]], device=None,
-                      bucket_bytes: int = 256 << 20) -> Iterator[Tuple[str, np.ndarray]]:
-    """Rank 0 supplies (name, array) in tensor_specs order; every rank yields the same sequence.  Tensors
-    travel in ~256 MB buckets (few, large broadcasts: xGMI is point-to-point, so per-call latency and
-    per-link bandwidth, not switch fan-out, set the cost)."""
+                      bucket_bytes: int = 256 << 20, bf16_matrices: bool = False) -> Iterator[Tuple[str, object]]:
+    """Rank 0 supplies (name, array) in tensor_specs order; every rank yields the same sequence.  Tensors travel in
+    ~256 MB buckets (few, large broadcasts: xGMI is point-to-point, so per-call latency and per-link bandwidth, not
+    switch fan-out, set the cost).
+
+    RCCL ("nccl") backend: the buckets live in device memory and are handed to the engine as DeviceTensor views - GPU to
+    GPU over xGMI, no host staging on the receiving ranks; with `bf16_matrices` (bf16 engines) the weight matrices are
+    rounded to bf16 ONCE on rank 0 and travel as bf16 (3.1 GB instead of 6.2 GB for large-v3; every rank, rank 0
+    included, loads the same bits).  gloo backend (CPU tests): float32 host buckets, host arrays out."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
         yield from src_iter
         return
+    from .engine import DeviceTensor
     rank = dist.get_rank()
-    dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
+    on_dev = not (device is None or dist.get_backend() == "gloo")
+    dev = torch.device(f"cuda:{device}") if on_dev else torch.device("cpu")
     specs = synth.tensor_specs(dims)
     it = iter(src_iter) if rank == 0 else None
+
+    def dtype_of(k):
+        return torch.bfloat16 if (on_dev and bf16_matrices and _is_matrix(specs[k][0], specs[k][1])) else torch.float32
+
     i = 0
     while i < len(specs):
-        j, nbytes = i, 0
-        while j < len(specs) and (j == i or nbytes + 4 * int(np.prod(specs[j][1])) <= bucket_bytes):
-            nbytes += 4 * int(np.prod(specs[j][1]))
+        dt = dtype_of(i)
+        esz = 2 if dt == torch.bfloat16 else 4
+        j, n_el = i, 0
+        while j < len(specs) and dtype_of(j) == dt and (j == i or (n_el + int(np.prod(specs[j][1]))) * esz <= bucket_bytes):
+            n_el += int(np.prod(specs[j][1]))
             j += 1
-        n_el = nbytes // 4
         if rank == 0:
-            parts = []
+            flat = torch.empty(n_el, dtype=dt, device=dev)
+            off = 0
             for k in range(i, j):
                 name, arr = next(it)
                 assert name == specs[k][0] and tuple(arr.shape) == tuple(specs[k][1]), (name, specs[k])
-                parts.append(np.ascontiguousarray(arr, dtype=np.float32).ravel())
-            flat = torch.from_numpy(np.concatenate(parts)).to(dev)
+                n = int(np.prod(specs[k][1]))
+                flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).ravel()).to(dev).to(dt)
+                off += n
         else:
-            flat = torch.empty(n_el, dtype=torch.float32, device=dev)
+            flat = torch.empty(n_el, dtype=dt, device=dev)
         dist.broadcast(flat, src=0)
-        host = flat.cpu().numpy()
-        off = 0
-        for k in range(i, j):
-            n = int(np.prod(specs[k][1]))
-            yield specs[k][0], host[off:off + n].reshape(specs[k][1])
-            off += n
+        if on_dev:
+            torch.cuda.synchronize(dev)   # the engine reads the bucket on its own stream
+            off = 0
+            for k in range(i, j):
+                n = int(np.prod(specs[k][1]))
+                yield specs[k][0], DeviceTensor(flat.data_ptr() + off * esz, 1 if dt == torch.bfloat16 else 0, tuple(specs[k][1]))
+                off += n
+            del flat                      # the consumer has loaded every view (load_weights is synchronous)
+        else:
+            host = flat.numpy()
+            off = 0
+            for k in range(i, j):
+                n = int(np.prod(specs[k][1]))
+                yield specs[k][0], host[off:off + n].reshape(specs[k][1])
+                off += n
         i = j
 
 
 def broadcast_weights(engine, dims: WhisperDims, src_iter, device=None):
-    engine.load_weights(broadcast_tensors(dims, src_iter, device))
+    from .config import COMPUTE_BF16
+    engine.load_weights(broadcast_tensors(dims, src_iter, device, bf16_matrices=engine.compute_type == COMPUTE_BF16))
 
 
 def gather_tokens(tokens: Sequence[Sequence[int]], max_len: int, device=None, pad: int = -1) -> np.ndarray:

@@ -17,6 +17,14 @@ class TtasrError(RuntimeError):
 
 
 @dataclass
+class DeviceTensor:
+    """A tensor in device memory of the engine's GPU: address, TTASR_DTYPE_* (0 float32, 1 bfloat16 bits), shape."""
+    ptr: int
+    dtype: int
+    shape: Tuple[int, ...]
+
+
+@dataclass
 class GenResult:
     tokens: List[List[int]]
     sum_logprob: np.ndarray
@@ -28,9 +36,14 @@ def _ptr(a: np.ndarray):
 
 
 def default_suppress(st: SpecialTokens, vocab: int) -> List[int]:
-    """suppress_tokens=[-1] of faster-whisper: non-speech symbols + task/sot/prev/no-speech specials."""
+    """suppress_tokens=[-1] of faster-whisper (get_suppressed_tokens): the non-speech symbols plus <|transcribe|>,
+    <|translate|>, <|startoftranscript|>, <|startofprev|>, <|startoflm|>; <|nospeech|> is masked as well, as in the
+    generation_config.json of the released checkpoints and openai-whisper (its probability is read from the raw logits
+    before the mask, and it is never a legitimate output)."""
     ids = [t for t in NON_SPEECH_TOKENS_MULTI if t < min(vocab, st.eot)]
     ids += [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]
+    if st.sot_lm >= 0:
+        ids.append(st.sot_lm)
     return sorted(set(ids))
 
 
@@ -68,8 +81,15 @@ class Engine:
             pass
 
     # -- weights -------------------------------------------------------------------------------
-    def load_weights(self, tensors: Iterable[Tuple[str, np.ndarray]]):
+    def load_weights(self, tensors: Iterable[Tuple[str, "np.ndarray | DeviceTensor"]]):
+        """(name, float32 host array) pairs, or (name, DeviceTensor) for tensors already resident in this GPU's memory
+        (the multi-GPU start-up: dist.broadcast_weights hands over the RCCL buckets without a host round trip)."""
         for name, arr in tensors:
+            if isinstance(arr, DeviceTensor):
+                dims = (C.c_int64 * len(arr.shape))(*arr.shape)
+                self._check(self.lib.ttasr_load_tensor_device(self.h, name.encode(), C.c_void_p(arr.ptr), arr.dtype, dims,
+                                                              len(arr.shape)), f"load_tensor_device({name})")
+                continue
             a = np.ascontiguousarray(arr, dtype=np.float32)
             dims = (C.c_int64 * a.ndim)(*a.shape)
             self._check(self.lib.ttasr_load_tensor(self.h, name.encode(), _ptr(a), dims, a.ndim), f"load_tensor({name})")

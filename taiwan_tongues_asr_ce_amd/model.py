@@ -197,6 +197,11 @@ class WhisperModel:
                 with open(gc_path, "r", encoding="utf-8") as f:
                     heads = json.load(f).get("alignment_heads")
         self.alignment_heads = [tuple(h) for h in heads] if heads else alignment.default_alignment_heads(dims.dec_layers, dims.n_heads)
+        if compute_type in ("float16", "fp16", "int8_float16", "int8_bfloat16", "int8"):
+            # the reference asks for float16 on GPU (asr_core.py:141) and int8 on CPU (api/file_asr.py:188); this engine's
+            # 16-bit type is bfloat16 and it has no int8 path - say so instead of silently computing in another type
+            warnings.warn(f"compute_type={compute_type!r} is not implemented by this engine: computing in bfloat16 "
+                          "(bf16 weights and activations, f32 accumulation, LayerNorm and softmax)", stacklevel=2)
         self.engine = Engine(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
         self.engine.load_weights(tensors)
         self.special = self.engine.special
@@ -331,10 +336,11 @@ class WhisperModel:
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         if beam_size < 1:
             raise ValueError("beam_size must be >= 1")
-        if beam_size > min(7, self.max_batch):
-            warnings.warn(f"beam_size={beam_size} exceeds this model's row budget (max_batch={self.max_batch}, kernel limit 7): "
-                          "decoding greedily", stacklevel=2)
-            beam_size = 1
+        if beam_size > 7:
+            raise ValueError(f"beam_size={beam_size}: the beam-search kernel keeps at most 7 hypotheses per clip")
+        if beam_size > self.max_batch:
+            raise ValueError(f"beam_size={beam_size} needs {beam_size} decode rows but this model was built with "
+                             f"max_batch={self.max_batch}; construct WhisperModel(..., max_batch>={beam_size})")
         chunks = None
         if vad_filter:
             # faster-whisper: Silero VAD -> speech chunks -> transcribe their concatenation -> restore the time line.
@@ -394,10 +400,19 @@ class WhisperModel:
 
     @staticmethod
     def _needs_fallback(avg_lp, ns, cr, p) -> bool:
-        if p["no_speech_threshold"] is not None and ns > p["no_speech_threshold"]:
-            return False  # silence: do not retry
-        return (p["compression_ratio_threshold"] is not None and cr > p["compression_ratio_threshold"]) or \
-               (p["log_prob_threshold"] is not None and avg_lp < p["log_prob_threshold"])
+        """faster-whisper generate_with_fallback: retry at the next temperature when the text is too repetitive or too
+        unlikely; the retry is cancelled only for a window that is BOTH probably silent and unlikely (no_speech_prob above
+        its threshold, log_prob_threshold set and avg_logprob below it) - a silent-looking window with an acceptable
+        log-probability but a high compression ratio is still retried."""
+        needs = False
+        if p["compression_ratio_threshold"] is not None and cr > p["compression_ratio_threshold"]:
+            needs = True
+        if p["log_prob_threshold"] is not None and avg_lp < p["log_prob_threshold"]:
+            needs = True
+        if p["no_speech_threshold"] is not None and ns > p["no_speech_threshold"] and \
+                p["log_prob_threshold"] is not None and avg_lp < p["log_prob_threshold"]:
+            needs = False  # silence
+        return needs
 
     def _decode_with_fallback(self, prompt, opts, seek: int, p, first=None):
         """generate_with_fallback for the clip resident at index 0: temperature 0 = beam/greedy (or `first`, an already

@@ -211,3 +211,33 @@ def test_prompt_with_hotwords_and_prefix():
     assert p == [st.sot, st.lang_zh, st.transcribe, st.no_timestamps, 700, 701, 702] and sot == 0
     p, _ = m._prompt(st.lang_zh, "transcribe", False, list(range(1000, 1400)), list(range(2000, 2400)), None)
     assert len(p) == 448 - 32 and p[1:224] == list(range(2000, 2223)) and p[224] == 1400 - (448 - 32 - 227)   # previous text gives way
+
+
+def test_fallback_rule_matches_faster_whisper_generate_with_fallback():
+    """faster-whisper retries a window at the next temperature when it is too repetitive or too unlikely, and cancels the
+    retry only when the window is BOTH probably silent and unlikely (a silent-looking window with a fine
+    log-probability but a high compression ratio must still be retried)."""
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    p = dict(no_speech_threshold=0.6, log_prob_threshold=-1.0, compression_ratio_threshold=2.4)
+    f = WhisperModel._needs_fallback
+    assert f(-0.5, 0.1, 1.0, p) is False                      # fine
+    assert f(-0.5, 0.1, 3.0, p) is True                       # repetitive
+    assert f(-1.5, 0.1, 1.0, p) is True                       # unlikely
+    assert f(-1.5, 0.9, 1.0, p) is False                      # silent AND unlikely: accepted (and skipped later)
+    assert f(-0.5, 0.9, 3.0, p) is True                       # silent-looking but likely and repetitive: retried
+    assert f(-1.5, 0.9, 3.0, p) is False
+    assert f(-1.5, 0.9, 3.0, dict(p, log_prob_threshold=None)) is True      # no log-prob threshold: nothing cancels
+    assert f(-9.0, 0.0, 9.0, dict(no_speech_threshold=None, log_prob_threshold=None, compression_ratio_threshold=None)) is False
+
+
+def test_default_suppress_list_has_startoflm_like_the_reference():
+    from taiwan_tongues_asr_ce_amd.config import SpecialTokens
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    for vocab, sot_lm in ((51865, 50360), (51866, 50361)):
+        st = SpecialTokens.for_vocab(vocab)
+        assert st.sot_lm == sot_lm == st.sot_prev - 1
+        ids = default_suppress(st, vocab)
+        assert {st.transcribe, st.translate, st.sot, st.sot_prev, st.sot_lm} <= set(ids)
+        assert st.eot not in ids and st.no_timestamps not in ids and all(i < st.timestamp_begin for i in ids)
+    st = SpecialTokens.for_vocab(512)                          # synthetic vocabularies have no <|startoflm|>
+    assert st.sot_lm == -1 and -1 not in default_suppress(st, 512)

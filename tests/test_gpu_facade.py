@@ -90,7 +90,29 @@ def test_asr_adapter_result_dict():
                                    get_file_name=lambda: "c1_0.wav")
     out = asyncio.run(asr.transcribe(client))
     assert out is None or set(out) == {"language", "language_probability", "final", "text", "duration", "words"}
+    # the adapter really decodes with the reference's options (beam 5, faster_whisper_asr.py:139-149): its text is the text
+    # of a direct transcribe(beam_size=5) call on the same model, and the model has the rows that beam needs
+    assert asr.asr_pipeline.max_batch >= 5
+    audio = np.frombuffer(pcm, dtype="<i2").astype(np.float32) / 32768.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        segs, _ = asr.asr_pipeline.transcribe(audio, language="zh", **asr.default_transcribe_kwargs)
+        direct = " ".join(s.text.strip() for s in segs)
+    assert (out["text"] if out else "") == direct
     asr.warm_up()
+
+
+def test_beam_that_does_not_fit_is_refused_not_degraded():
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    m = WhisperModel("synthetic:micro", device="cuda", compute_type="float32", max_batch=2)
+    with pytest.raises(ValueError, match="max_batch"):
+        m.transcribe(np.zeros(1600, np.float32), language="zh", beam_size=5)
+    with pytest.raises(ValueError, match="at most 7"):
+        m.transcribe(np.zeros(1600, np.float32), language="zh", beam_size=9)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        WhisperModel("synthetic:micro", device="cuda", compute_type="float16", max_batch=1)
+    assert any("computing in bfloat16" in str(x.message) for x in w)
 
 
 def test_fallback_ladder_runs_and_reports_temperature(model):
@@ -147,7 +169,7 @@ def test_ct2_directory_loads_like_the_same_weights_in_memory(tmp_path):
     variables, aliases = ct2.hf_to_ct2(hf.items(), dims, dtype=np.float16)
     ct2.write_model_bin(str(tmp_path / "model.bin"), variables, aliases)
     (tmp_path / "config.json").write_text("{}", encoding="utf-8")
-    m = WhisperModel(str(tmp_path), device="cuda", compute_type="float32", max_batch=2)
+    m = WhisperModel(str(tmp_path), device="cuda", compute_type="float32", max_batch=8)   # the folder tool decodes with beam 5
     assert (m.dims.d_model, m.dims.enc_layers, m.dims.vocab) == (dims.d_model, dims.enc_layers, dims.vocab)
     eng = m.engine
     clip = synth.noise_clip(3)[: dims.n_frames * 160]

@@ -28,10 +28,10 @@ def _agree(a, b):
 
 
 def _same_prefix_fraction(rows_a, rows_b, k):
-    """Fraction of rows whose first k tokens agree.  The bf16 decode path sums split-K partial products with f32
-    atomics, so two runs differ in the last bits of the logits and a near-tie (random-init weights give many:
-    top-2 margins of 0.01-0.1 on logits of std 1.8) can flip; after a flip the row's continuation differs.  The
-    f32 parity mode has no atomics and is bit-reproducible."""
+    """Fraction of rows whose first k tokens agree (used where the two runs go through DIFFERENT kernels - a clip alone
+    takes other GEMM tiles than the same clip inside a batch of 32 - so the last bits of the logits differ and a near-tie
+    of the random-init weights can flip).  Replays and re-orderings of the same batch are held to exact equality: the
+    bf16 path has no float atomics (K-split partial tiles are summed in a fixed order)."""
     return float(np.mean([a[:k] == b[:k] for a, b in zip(rows_a, rows_b)]))
 
 
@@ -61,17 +61,17 @@ def test_full_size_invariants(eng):
                 last_ts = t
             if i >= 2 and toks[i - 1] >= st.timestamp_begin and toks[i - 2] >= st.timestamp_begin:
                 assert t < st.timestamp_begin, "a timestamp pair must be followed by text"
-    # determinism of a replay (same graph, same state): split-K float atomics may reorder sums, so allow a late
-    # divergence but the early tokens must be identical
+    # a replay is bit-identical: tokens, scores and no-speech probabilities (no float atomics in the bf16 path)
     res2 = e.generate([prompt] * B, opts)
-    assert _same_prefix_fraction(res.tokens, res2.tokens, 8) >= 0.9
-    assert np.mean([_agree(a, b) for a, b in zip(res.tokens, res2.tokens)]) > 0.8
-    # clip-order equivariance: reversing the batch reverses the rows
+    assert res2.tokens == res.tokens
+    assert np.array_equal(res2.sum_logprob, res.sum_logprob) and np.array_equal(res2.no_speech_prob, res.no_speech_prob)
+    # clip-order equivariance, exactly: every kernel of the path computes a row independently of its batch position
     e.log_mel(clips[::-1], want_output=False)
     e.encode(B)
     rev = e.generate([prompt] * B, opts)
-    assert _same_prefix_fraction(res.tokens, rev.tokens[::-1], 8) >= 0.9
-    np.testing.assert_allclose(res.no_speech_prob, rev.no_speech_prob[::-1], rtol=0.05, atol=1e-6)
+    assert rev.tokens[::-1] == res.tokens
+    assert np.array_equal(rev.sum_logprob[::-1], res.sum_logprob)
+    assert np.array_equal(rev.no_speech_prob[::-1], res.no_speech_prob)
     # a clip alone (B = 1: split cross-attention, 256x128 GEMM tiles) == its row in the batch of 32, early tokens
     solo_rows, batch_rows = [], []
     for b in (5, 17, 30):
@@ -132,7 +132,8 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights():
     """Same full model in the MEASURED mode (bf16): against the f32 oracle holding the bf16-rounded weights the encoder
     output stays within 0.06 (measured 0.023 max, 0.0026 mean on LayerNorm-scale values) and the prompt logits within
     0.08 (measured 0.032 on logits of std 1.8); under teacher forcing every greedy choice is within 0.15 of the oracle's
-    best allowed logit (measured: identical argmax at all positions)."""
+    best allowed logit, and IDENTICAL to the oracle's choice wherever the oracle's top-2 margin exceeds 2 x that tolerance
+    (measured: identical argmax at all positions)."""
     import torch
     from oracle import whisper_ref as R
     from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
@@ -165,7 +166,14 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights():
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False)
     assert len(toks) == 8
+    n_clear = 0
     for i, t in enumerate(toks):
         s = R.apply_rules(logits[0], toks[:i], rules)
+        top2 = np.sort(np.asarray(s))[-2:]
+        # token equality wherever the oracle's own top-2 margin exceeds 2 x the logit tolerance stated above (0.08)
+        if top2[1] - top2[0] > 0.16:
+            assert int(np.argmax(s)) == t, (i, t, int(np.argmax(s)))
+            n_clear += 1
         assert s[t] > -np.inf and float(s.max() - s[t]) < 0.15, i
         logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[:, 0]
+    assert n_clear >= 1

@@ -1,0 +1,81 @@
+"""GPU: the device-side weight intake (ttasr_load_tensor_device: what the RCCL broadcast hands over, f32 or bf16 bits,
+no host staging) gives bit-identical engines to the host intake; `python bench.py --gpus 2` launches itself from a bare
+shell (two ranks sharing this box's one GPU over gloo: RCCL refuses two ranks per device, so this is the plumbing check -
+weight broadcast, sharded clips, token gather, rank-to-rank logits validation)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, PRESETS
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("compute", [COMPUTE_BF16, COMPUTE_F32])
+def test_device_weight_intake_is_bit_identical_to_host_intake(compute):
+    import torch
+    from taiwan_tongues_asr_ce_amd.dist import _is_matrix
+    from taiwan_tongues_asr_ce_amd.engine import DeviceTensor, Engine
+    dims = PRESETS["tiny"]
+    clips = [synth.noise_clip(0), synth.tonal_clip(1)]
+    outs = []
+    for route in ("host", "device"):
+        e = Engine(dims, compute, 2)
+        if route == "host":
+            e.load_weights(synth.iter_weights(dims))
+        else:
+            keep = []
+
+            def views():
+                for name, arr in synth.iter_weights(dims):
+                    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).cuda()
+                    as_bf16 = compute == COMPUTE_BF16 and _is_matrix(name, arr.shape)   # what dist.broadcast_weights sends
+                    if as_bf16:
+                        t = t.to(torch.bfloat16)
+                    torch.cuda.synchronize()
+                    keep.append(t)
+                    yield name, DeviceTensor(t.data_ptr(), 1 if as_bf16 else 0, tuple(arr.shape))
+            e.load_weights(views())
+        st = e.special
+        e.log_mel(clips, want_output=False)
+        enc = e.encode(2, want_output=True)
+        e.decode_reset(2)
+        lg = [e.decode_step([t, t]) for t in (st.sot, st.lang_zh, st.transcribe)]
+        outs.append((enc, lg))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+
+
+def test_device_intake_rejects_bad_arguments():
+    import ctypes as C
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    e = Engine(PRESETS["micro"], COMPUTE_F32, 1)
+    dims = (C.c_int64 * 1)(128)
+    assert e.lib.ttasr_load_tensor_device(e.h, b"model.encoder.layer_norm.weight", None, 0, dims, 1) != 0
+    assert e.lib.ttasr_load_tensor_device(e.h, b"model.encoder.layer_norm.weight", C.c_void_p(16), 7, dims, 1) != 0
+    assert b"dtype" in e.lib.ttasr_last_error(e.h)
+    e.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """The driver's invocation form: `python bench.py --gpus 2` with no torchrun environment."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--batch", "2",
+                        "--steps", "2", "--warmup", "1", "--new-tokens", "8", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["clips_per_gpu"] == 2
+    assert out["config"]["rank_logits_spread"] == 0.0          # both ranks hold the same broadcast weights, bit for bit
+    assert "share GPUs over gloo" in out["config"]["parallelism"]

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""A/B timing of the decode launch plans on one GPU (large-v3 geometry, B = 32, bf16, 4 + 128 greedy tokens):
+every variant is an environment setting read by ttasr_create, so one process times them all on the same clips.
+Also checks that each variant is bit-reproducible (three replays give identical tokens and scores) and reports
+how many rows agree token-for-token between variants.  One JSON line per variant.
+
+    python tools/decode_variants.py [--variants name,name] [--batch 32] [--new-tokens 128]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {
+    "auto": {},                                            # default plan: K slices chosen automatically (d 4, q 4, qkv 4, fc2 8)
+    "qkv2": {"TTASR_KS": "4,4,2,8"},
+    "qkv1_q1": {"TTASR_KS": "4,1,1,8"},                    # only the residual GEMMs split (round-1 shape, slabs instead of atomics)
+    "d5_f16": {"TTASR_KS": "5,4,4,16"},
+    "d2_f4": {"TTASR_KS": "2,2,2,4"},
+    "dual": {"TTASR_DUAL": "1"},
+    "xattn_plain": {"TTASR_XATTN": "0"},
+}
+KNOBS = sorted({k for v in VARIANTS.values() for k in v})
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--new-tokens", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--env", action="append", default=[], help="extra NAME=VALUE applied to every variant")
+    ap.add_argument("--xattn-sweep", action="store_true",
+                    help="time the cross-attention kernel variants (TTASR_XATTN 0..7) in isolation instead")
+    args = ap.parse_args()
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+
+    dims = PRESETS[args.model]
+    B = args.batch
+    clips = [synth.noise_clip(b) for b in range(B)]
+    weights = list(synth.iter_weights(dims))
+    if args.xattn_sweep:
+        import ctypes
+        e = Engine(dims, COMPUTE_BF16, B)
+        e.load_weights(weights)
+        e.log_mel(clips, want_output=False)
+        e.encode(B)
+        var = ctypes.c_int.in_dll(e.lib, "g_xattn_variant")
+        for rep in range(2):
+            for v in range(8):
+                var.value = v
+                k = e.bench_kernel("xattn", B, iters=96)
+                print(json.dumps({"xattn_variant": v, "waves": 8 if v & 4 else 4, "nontemporal": bool(v & 1),
+                                  "rows_in_flight": (4 if v & 2 else 8) if v & 4 else (16 if v & 2 else 8),
+                                  "us": round(k["ms"] * 1e3, 2), "TBps": round(k["bytes"] / k["ms"] / 1e9, 3)}), flush=True)
+        e.close()
+        return
+    first = None
+    for name in args.variants.split(","):
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update(VARIANTS[name])
+        for kv in args.env:
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+        e = Engine(dims, COMPUTE_BF16, B)
+        e.load_weights(weights)
+        st = e.special
+        e.log_mel(clips, want_output=False)
+        e.encode(B)
+        prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+        opts = e.gen_opts(args.new_tokens, timestamps=False, suppress_eot=True, no_speech=True, check_interval=1 << 20)
+        runs, ms, wall = [], [], []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            r = e.generate([prompt] * B, opts)
+            wall.append((time.perf_counter() - t0) * 1e3)
+            ms.append(e.phase_ms()["decode"])
+            runs.append(r)
+        same = all(r.tokens == runs[0].tokens and np.array_equal(r.sum_logprob, runs[0].sum_logprob) for r in runs[1:])
+        if first is None:
+            first = runs[0]
+        agree = float(np.mean([a == b for a, b in zip(first.tokens, runs[0].tokens)]))
+        n_steps = 4 + args.new_tokens - 1
+        print(json.dumps({"variant": name, "env": VARIANTS[name], "decode_ms": round(min(ms[1:]), 2),
+                          "ms_per_step": round(min(ms[1:]) / n_steps, 4), "wall_ms": round(min(wall[1:]), 2),
+                          "bit_reproducible": bool(same), "rows_equal_to_first_variant": agree}), flush=True)
+        e.close()
+
+
+if __name__ == "__main__":
+    main()
