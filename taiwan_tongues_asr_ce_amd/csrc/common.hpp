@@ -37,6 +37,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Kernel arguments live in the kernarg segment and reach SGPRs through s_load; the compiler treats those loads as free to
+// re-materialise and sinks them next to their first use, which in these kernels produced two or three SERIALISED
+// round trips (pointer -> wait -> address -> second pointer -> wait ...) in front of the first weight load - about a
+// microsecond each in a decode chain whose kernels only take 3-8.  Passing every argument through an empty asm at kernel
+// entry makes the values opaque, so all s_loads are issued together, once.
+template <class T> __device__ __forceinline__ T sgpr_pin(T v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+template <class T> __device__ __forceinline__ T* sgpr_pin_ptr(T* p) {
+  typedef __attribute__((address_space(1))) T* global_ptr;  // stay in the global address space: no flat_load fallback
+  global_ptr g = (global_ptr)p;
+  asm volatile("" : "+s"(g));
+  return (T*)g;
+}
+
+
 // ---- GEMM epilogue description (shared by every GEMM flavour) ------------------------------------
 // C[m][n] = act(alpha-free acc + bias[n]) (+ rowtab[(m % rowmod)][n]) (+ residual[m][n]); written as f32
 // and/or T.  headsplit != 0 scatters T output into the cross-KV layout [which][b][h][t][64].
@@ -170,6 +187,7 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
                               int Tk, int kv_div, hipStream_t s,
                               float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/,
                               SlabIn sq = SlabIn{} /*q from K-split partial tiles*/);
+extern int g_skinny_nt;     // TTASR_W_NT: nontemporal weight loads in the decode GEMMs (A/B experiments)
 extern int g_xattn_variant;  // TTASR_XATTN: cross-attention kernel variant (A/B experiments)
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
 // per-row history state uploaded by the host)

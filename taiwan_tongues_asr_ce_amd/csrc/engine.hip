@@ -59,6 +59,7 @@ struct ttasr_ctx {
   int T = 0, F = 0, d = 0, H = 0, ffn = 0, V = 0, ldv = 0, M = 0, maxB = 0, n_samples = 0;
   int pages_per_seq = 0;
   std::vector<void*> allocs;
+  struct Pool { char* base = nullptr; size_t cap = 0, used = 0; } small_pool, big_pool;  // bump arenas (see dalloc)
   std::unordered_map<std::string, Slot> slots;
 
   // weights
@@ -132,13 +133,28 @@ int fail(ttasr_ctx* c, int code, const char* fmt, ...) {
                                       __FILE__, __LINE__);                                                    \
   } while (0)
 
+// Device memory comes from a few large arenas, not one hipMalloc per tensor: the decode step is ~350 dependent launches
+// whose first access is to a small, rarely touched buffer (LayerNorm gamma / beta, a bias, the residual rows).  With ~2500
+// separate allocations every one of those sat on its own page, and after the ~10 GB a step streams (weights + cross-KV)
+// each launch opened with an address-translation miss.  The small pool (< 1 MiB requests: every vector, every decode
+// activation) is one 64 MiB block that stays translation- and cache-resident; matrices and KV pools come from 1 GiB+
+// blocks that the driver can map with its largest page fragments.
 template <typename P>
 int dalloc(ttasr_ctx* c, P** p, size_t bytes, bool zero = true) {
-  void* q = nullptr;
   if (bytes == 0) bytes = 16;
-  hipError_t e = hipMalloc(&q, bytes);
-  if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-  c->allocs.push_back(q);
+  bytes = (bytes + 255) & ~(size_t)255;
+  ttasr_ctx::Pool& pool = bytes < (1u << 20) ? c->small_pool : c->big_pool;
+  if (pool.used + bytes > pool.cap) {
+    const size_t chunk = &pool == &c->small_pool ? (size_t)64 << 20 : (size_t)1 << 30;
+    const size_t cap = bytes > chunk ? bytes : chunk;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, cap);
+    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    c->allocs.push_back(q);
+    pool.base = (char*)q; pool.cap = cap; pool.used = 0;
+  }
+  void* q = pool.base + pool.used;
+  pool.used += bytes;
   if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
   *p = (P*)q;
   return 0;
@@ -457,7 +473,10 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   // K slices per GEMM kind (0 out-proj, 1 q, 2 qkv, 3 fc2); attention consumers sum at most 4 slabs
   auto slices = [&](int kind, int N, int K) {
     if (!skinny) return 1;
-    int ks = gemm_skinny_ksplit(n, N, K, c->ks_want[kind]);
+    int want = c->ks_want[kind];
+    // qkv (N = 3 d: already 3x the workgroups of the other GEMMs): 2 slices measured best (5.35 vs 6.02 us at large-v3)
+    if (kind == 2 && want == 0 && (N + 31) / 32 >= 96) want = 2;
+    int ks = gemm_skinny_ksplit(n, N, K, want);
     if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
     return ks;
   };
@@ -769,6 +788,8 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->no_flash = getenv("TTASR_NO_FLASH") != nullptr;
   if (const char* v = getenv("TTASR_GEMM")) c->gemm_force = (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0;
   if (const char* v = getenv("TTASR_XATTN")) g_xattn_variant = atoi(v);
+  // nontemporal weight loads: the 1.8 GB of decoder weights a step streams can never stay cached (measured -1 % per step)
+  g_skinny_nt = getenv("TTASR_W_NT") ? atoi(getenv("TTASR_W_NT")) : 1;
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
   if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));

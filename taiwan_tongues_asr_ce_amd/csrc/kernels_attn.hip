@@ -114,12 +114,13 @@ __device__ __forceinline__ void load_row_slabs(const SlabIn& si, int64_t off, fl
 #pragma unroll
     for (int c = 0; c < NF4; ++c) t[s][c] = *(const float4*)(p + 4 * c);
   }
+  __builtin_amdgcn_sched_barrier(0);  // all loads issued before the first use: one round trip
 #pragma unroll
   for (int c = 0; c < NF4; ++c) {
     float4 a = bs[c];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-      if (s < si.n) { a.x += t[s][c].x; a.y += t[s][c].y; a.z += t[s][c].z; a.w += t[s][c].w; }
+    for (int s = 0; s < MAXS; ++s)   // slab 0 unconditionally (n >= 1): its load must not be sunk behind a branch
+      if (s == 0 || s < si.n) { a.x += t[s][c].x; a.y += t[s][c].y; a.z += t[s][c].z; a.w += t[s][c].w; }
     v[4 * c] = to_f<T>(from_f<T>(a.x)); v[4 * c + 1] = to_f<T>(from_f<T>(a.y));
     v[4 * c + 2] = to_f<T>(from_f<T>(a.z)); v[4 * c + 3] = to_f<T>(from_f<T>(a.w));
   }
@@ -157,22 +158,45 @@ using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 // grid row b is position (b % npos) of sequence (b / npos); launch 1 only appends every position's k,v to the
 // pool, launch 2 attends causally (keys 0..pos-1 from the pool, its own from registers) without appending - two
 // launches because a position reads keys that other workgroups of the first launch write.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restrict__ qkv, T* __restrict__ pool,
-                                                               const int32_t* __restrict__ page_table, int pages_per_seq,
-                                                               int identity_pages, int row0,
-                                                               const int32_t* __restrict__ step, T* __restrict__ out, int H,
-                                                               int npos, SlabIn sq) {
+template <typename T, int MODE, bool SLAB, bool IDENT>
+__global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* pool, const int32_t* page_table,
+                                                               int pages_per_seq, int identity_pages, int row0,
+                                                               const int32_t* step, T* out, int H, int npos, SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
   __shared__ float part[4][64];
   __shared__ float red[4][2];
+  // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin)
+  qkv = sgpr_pin_ptr(qkv); pool = sgpr_pin_ptr(pool); page_table = sgpr_pin_ptr(page_table); step = sgpr_pin_ptr(step);
+  out = sgpr_pin_ptr(out);
+  pages_per_seq = sgpr_pin(pages_per_seq); identity_pages = sgpr_pin(identity_pages); row0 = sgpr_pin(row0); H = sgpr_pin(H);
+  npos = sgpr_pin(npos);
+  sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
+  sq.ld = sgpr_pin(sq.ld);
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64, pos = MODE == 0 ? *step : b % npos;
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
   const int sub = lane % LPR, rin = lane / LPR;
+  // global row: qkv / out are already offset to the half-batch, the KV pages are not
+  const int bg = MODE == 0 ? b + row0 : b / npos;
+  const int32_t* pt = page_table + bg * pages_per_seq;
+  // IDENT (greedy decoding never re-indexes the table): the page id is computed, not loaded - no dependent load
+  auto page_of = [&](int t) { return IDENT ? bg * pages_per_seq + t / PAGE : pt[t / PAGE]; };
+  // this lane's slot: rows t = (it*4 + wave)*RPI + rin of the cached keys 0..pos-1.  The first batch of cached rows is
+  // requested BEFORE q, k, v of this step are fetched (their addresses depend on the position only): one round trip less
+  float kv[UNROLL][VEC], vv[UNROLL][VEC];
+  auto load_kv = [&](int it0) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int tc = max(min(((it0 + u) * 4 + wave) * RPI + rin, pos - 1), 0);  // clamped, unconditional loads
+      const int64_t base = ((int64_t)page_of(tc) * 2 * H + h) * PAGE + (tc % PAGE);
+      RowVec<T>::load(pool + base * 64 + sub * VEC, kv[u]);
+      RowVec<T>::load(pool + (base + (int64_t)H * PAGE) * 64 + sub * VEC, vv[u]);
+    }
+  };
+  if (MODE != 1) load_kv(0);
   float q[VEC], kn[VEC], vn[VEC];
-  if (MODE == 0 && sq.n > 0) {  // qkv GEMM was K-split: complete q, k, v from its partial tiles
+  if constexpr (SLAB) {  // qkv GEMM was K-split: complete q, k, v from its partial tiles
     // waves 0 / 1 / 2 sum q / k / v (their first LPR lanes, one 16-byte chunk each) and share them through LDS:
     // 24 lanes issue the slab loads instead of all 256
     __shared__ float qkv_s[3][64];
@@ -190,10 +214,6 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
     RowVec<T>::load(qp + d + sub * VEC, kn);
     RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
   }
-  // global row: qkv / out are already offset to the half-batch, the KV pages are not
-  const int bg = MODE == 0 ? b + row0 : b / npos;
-  const int32_t* pt = page_table + bg * pages_per_seq;
-  auto page_of = [&](int t) { return identity_pages ? bg * pages_per_seq + t / PAGE : pt[t / PAGE]; };
   if (MODE != 2 && wave == 0 && rin == 0) {  // append this step's k, v
     const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
@@ -202,20 +222,12 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* __restri
     store_row<T>(vdst + sub * VEC, vn);
   }
   if (MODE == 1) return;
-  // this lane's slot: rows t = (it*4 + wave)*RPI + rin of the cached keys 0..pos-1
   float m_run = -1e30f, l_run = 0.f, acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
   const int n_it = (pos + 4 * RPI - 1) / (4 * RPI);
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    float kv[UNROLL][VEC], vv[UNROLL][VEC];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int tc = min(((it0 + u) * 4 + wave) * RPI + rin, pos - 1);  // clamped, unconditional loads
-      const int64_t base = ((int64_t)page_of(tc) * 2 * H + h) * PAGE + (tc % PAGE);
-      RowVec<T>::load(pool + base * 64 + sub * VEC, kv[u]);
-      RowVec<T>::load(pool + (base + (int64_t)H * PAGE) * 64 + sub * VEC, vv[u]);
-    }
+    if (it0 > 0) load_kv(it0);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int t = ((it0 + u) * 4 + wave) * RPI + rin;
@@ -277,17 +289,22 @@ template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                              int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s, SlabIn sq) {
   // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
-  hipLaunchKernelGGL((self_attn_decode_kernel<T, 0>), dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, page_table,
-                     pages_per_seq, identity_pages, row0, step, out, H, 1, sq);
+#define TTASR_SA(SLAB_, IDENT_)                                                                                              \
+  hipLaunchKernelGGL((self_attn_decode_kernel<T, 0, SLAB_, IDENT_>), dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, \
+                     page_table, pages_per_seq, identity_pages, row0, step, out, H, 1, sq)
+  if (sq.n > 0) { if (identity_pages) TTASR_SA(true, true); else TTASR_SA(true, false); }
+  else { if (identity_pages) TTASR_SA(false, true); else TTASR_SA(false, false); }
+#undef TTASR_SA
 }
 // prompt prefill: rows = n_seq * npos, row-major [sequence][position]; positions 0..npos-1 of every sequence
 template <typename T>
 void launch_self_attn_prefill(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
                               int identity_pages, T* out, int n_seq, int npos, int H, hipStream_t s) {
-  hipLaunchKernelGGL((self_attn_decode_kernel<T, 1>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
-                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{});
-  hipLaunchKernelGGL((self_attn_decode_kernel<T, 2>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv, kv_pool + pool_layer_off,
-                     page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{});
+#define TTASR_SP(MODE_, IDENT_)                                                                                                 \
+  hipLaunchKernelGGL((self_attn_decode_kernel<T, MODE_, false, IDENT_>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv,          \
+                     kv_pool + pool_layer_off, page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{})
+  if (identity_pages) { TTASR_SP(1, true); TTASR_SP(2, true); } else { TTASR_SP(1, false); TTASR_SP(2, false); }
+#undef TTASR_SP
 }
 template void launch_self_attn_prefill<float>(const float*, float*, const int32_t*, int, int64_t, int, float*, int, int, int, hipStream_t);
 template void launch_self_attn_prefill<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, bf16_t*, int, int, int,
@@ -339,34 +356,44 @@ template <typename T, bool NT> __device__ __forceinline__ void load_row(const T*
     RowVec<T>::load(p, v);
   }
 }
-template <typename T, bool PROBS, int NWV, int UNROLL, bool NT>
-__global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* __restrict__ q, const T* __restrict__ K,
-                                                                     const T* __restrict__ V, T* __restrict__ out, int H, int Tk,
-                                                                     int kv_div, const int* __restrict__ sel,
-                                                                     float* __restrict__ probs, SlabIn sq) {
+template <typename T, bool PROBS, int NWV, int UNROLL, bool NT, bool QSLAB>
+__global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q, const T* K, const T* V, T* out, int H, int Tk,
+                                                                     int kv_div, const int* sel, float* probs, SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
+  // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin): the K stream starts one round trip after launch
+  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out);
+  H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div);
+  if constexpr (PROBS) { sel = sgpr_pin_ptr(sel); probs = sgpr_pin_ptr(probs); }
+  sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
+  sq.ld = sgpr_pin(sq.ld);
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + Tk;          // [NWV][64]
   float* red = part + NWV * 64;   // [2 * NWV]
-  float qv[VEC];
-  if (!PROBS && sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);  // q GEMM was K-split
-  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
   const int bk = b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
   const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64;
   const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64;
   float mloc = -1e30f;
   // rows handled by this wave: t = (it*NWV + wave)*RPI + rin
   const int n_it = (Tk + NWV * RPI - 1) / (NWV * RPI);
-  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    float kv[UNROLL][VEC];
+  float kv[UNROLL][VEC];
+  auto load_k = [&](int it0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       int t = ((it0 + u) * NWV + wave) * RPI + rin;
       load_row<T, NT>(Kp + (int64_t)min(t, Tk - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
     }
+  };
+  // the first K batch goes out BEFORE the query is fetched (and, when the q GEMM was K-split, summed from its partial
+  // tiles): the stream starts one round trip after launch instead of two
+  load_k(0);
+  float qv[VEC];
+  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);  // q GEMM was K-split
+  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    if (it0 > 0) load_k(it0);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       int t = ((it0 + u) * NWV + wave) * RPI + rin;
@@ -600,8 +627,12 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
   const int nwv = (var & 4) ? 8 : 4;
   size_t lds = sizeof(float) * (Tk + nwv * 64 + 2 * nwv);
 #define TTASR_XA(NWV_, UN_, NT_)                                                                                          \
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
-                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq)
+  do {                                                                                                                    \
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_, true>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
+                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                               \
+    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_, false>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
+                            Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                                        \
+  } while (0)
   switch (var & 7) {
     case 1: TTASR_XA(4, 8, true); break;
     case 2: TTASR_XA(4, 16, false); break;
@@ -619,7 +650,7 @@ template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel, float* probs,
                              hipStream_t s) {
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{});
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false, false>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{});
 }
 template void launch_cross_attn_probs<float>(const float*, const float*, const float*, float*, int, int, int, const int*, float*,
                                              hipStream_t);

@@ -104,12 +104,23 @@ __device__ __forceinline__ float gumbel_noise(uint32_t key, int i) {
 __device__ __forceinline__ void step_ticket(int32_t* ticket, int total_rows, int32_t* step) {
   if (ticket && atomicAdd(ticket, 1) == total_rows - 1) { *ticket = 0; *step += 1; }
 }
-__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ logits, DecState st, RuleParams p,
-                                                      float* __restrict__ out_rows, int32_t* ticket, int total_rows) {
+__global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecState st, RuleParams p, float* out_rows,
+                                                      int32_t* ticket, int total_rows) {
   __shared__ ArgMax s_am[2][16];
   __shared__ float s_sum[3][16];
   __shared__ float s_b[8];
   __shared__ int s_i[4];
+  // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin)
+  logits = sgpr_pin_ptr(logits); out_rows = sgpr_pin_ptr(out_rows); ticket = sgpr_pin_ptr(ticket); total_rows = sgpr_pin(total_rows);
+  st.cur_tok = sgpr_pin_ptr(st.cur_tok); st.step = sgpr_pin_ptr(st.step); st.n_sampled = sgpr_pin_ptr(st.n_sampled);
+  st.last_tok = sgpr_pin_ptr(st.last_tok); st.pen_tok = sgpr_pin_ptr(st.pen_tok); st.last_ts = sgpr_pin_ptr(st.last_ts);
+  st.done = sgpr_pin_ptr(st.done); st.n_done = sgpr_pin_ptr(st.n_done); st.sum_logprob = sgpr_pin_ptr(st.sum_logprob);
+  st.no_speech = sgpr_pin_ptr(st.no_speech); st.out_tokens = sgpr_pin_ptr(st.out_tokens); st.prompt = sgpr_pin_ptr(st.prompt);
+  st.prompt_len = sgpr_pin_ptr(st.prompt_len); st.mask = sgpr_pin_ptr(st.mask);
+  p.V = sgpr_pin(p.V); p.ldv = sgpr_pin(p.ldv); p.max_prompt = sgpr_pin(p.max_prompt); p.max_new = sgpr_pin(p.max_new);
+  p.eot = sgpr_pin(p.eot); p.no_timestamps = sgpr_pin(p.no_timestamps); p.timestamp_begin = sgpr_pin(p.timestamp_begin);
+  p.no_speech = sgpr_pin(p.no_speech); p.sot_index = sgpr_pin(p.sot_index); p.timestamps = sgpr_pin(p.timestamps);
+  p.max_initial = sgpr_pin(p.max_initial); p.suppress_eot = sgpr_pin(p.suppress_eot);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (int64_t)b * p.ldv;
   const int step = *st.step;

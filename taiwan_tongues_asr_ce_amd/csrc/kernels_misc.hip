@@ -216,10 +216,17 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, T* 
 // branches around a load.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MAXS, bool EMBED>
-__global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, T* __restrict__ out, int d,
+__global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __restrict__ x_, const float* __restrict__ gamma_,
+                                                             const float* __restrict__ beta_, T* __restrict__ out_, int d_,
                                                              LnPre pre) {
   __shared__ float red[2][8];
+  // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin)
+  const float* x = sgpr_pin_ptr(x_); const float* gamma = sgpr_pin_ptr(gamma_); const float* beta = sgpr_pin_ptr(beta_);
+  T* out = sgpr_pin_ptr(out_);
+  const int d = sgpr_pin(d_);
+  pre.bias = sgpr_pin_ptr(pre.bias); pre.slab = sgpr_pin_ptr(pre.slab); pre.n_slab = sgpr_pin(pre.n_slab);
+  pre.slab_stride = sgpr_pin(pre.slab_stride); pre.x_out = sgpr_pin_ptr(pre.x_out);
+  if constexpr (EMBED) { pre.tok = sgpr_pin_ptr(pre.tok); pre.step = sgpr_pin_ptr(pre.step); pre.emb = sgpr_pin_ptr(pre.emb); pre.pos = sgpr_pin_ptr(pre.pos); }
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   const int nv = d >> 2, i = min(tid, nv - 1);
   const bool live = tid < nv;
@@ -246,10 +253,13 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
 #pragma unroll
       for (int s = 0; s < MAXS; ++s)
         sl[s] = ((const float4*)(pre.slab + (int64_t)min(s, pre.n_slab - 1) * pre.slab_stride + (int64_t)row * d))[i];
+      __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first use below: ONE round trip
       v.x += bs.x; v.y += bs.y; v.z += bs.z; v.w += bs.w;
+      // slab 0 always exists in this instantiation (n_slab >= 1): adding it unconditionally keeps its load from being sunk
+      // behind a branch (= a second, serialised round trip)
 #pragma unroll
       for (int s = 0; s < MAXS; ++s)
-        if (s < pre.n_slab) { v.x += sl[s].x; v.y += sl[s].y; v.z += sl[s].z; v.w += sl[s].w; }
+        if (s == 0 || s < pre.n_slab) { v.x += sl[s].x; v.y += sl[s].y; v.z += sl[s].z; v.w += sl[s].w; }
     }
   }
   if (live && (EMBED || MAXS > 0)) ((float4*)(pre.x_out + (int64_t)row * d))[i] = v;

@@ -58,13 +58,25 @@ void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, in
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
 // which is what amortises the per-step latency when more clips are in flight).
-template <int NW, int RB, int U>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh, const bf16_t* __restrict__ x,
-                                                              int B, int N, int K, int ksplit, GemmEpi e,
-                                                              float* __restrict__ slab, int64_t slab_stride) {
+int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (TTASR_W_NT=0 switches them off: A/B experiments)
+
+// ONE = the wave's k-steps fit one batch of loads (steps <= U): straight-line code.  (As a loop, the register reuse of
+// the next iteration forces an early s_waitcnt that, in the first iteration, waits for the bias / residual prefetch
+// before the bulk of the weight loads is even issued: one more serialised round trip.)
+template <int NW, int RB, int U, bool NT, bool ONE>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh_, const bf16_t* __restrict__ x_,
+                                                              int B_, int N_, int K_, int ksplit_, GemmEpi e,
+                                                              float* __restrict__ slab_, int64_t slab_stride_) {
   // U = k-steps in flight per wave (register budget: U * (1 + RB) * 4); the launcher picks the smallest instantiated
   // U >= steps so that no load is issued twice
   __shared__ __attribute__((aligned(16))) float red[NW][RB][32 * 32];  // [wave][row group][b*32 + n]
+  const bf16_t* Wsh = sgpr_pin_ptr(Wsh_);
+  const bf16_t* x = sgpr_pin_ptr(x_);
+  const int B = sgpr_pin(B_), N = sgpr_pin(N_), K = sgpr_pin(K_), ksplit = sgpr_pin(ksplit_);
+  float* slab = sgpr_pin_ptr(slab_);
+  const int64_t slab_stride = sgpr_pin(slab_stride_);
+  e.bias = sgpr_pin_ptr(e.bias); e.residual = sgpr_pin_ptr(e.residual); e.out_f32 = sgpr_pin_ptr(e.out_f32);
+  e.out_t = sgpr_pin_ptr(e.out_t); e.ldc = sgpr_pin(e.ldc); e.act = sgpr_pin(e.act);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
   const int ks_per = K / 16;
@@ -74,39 +86,63 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   const bf16_t* xp[RB];
 #pragma unroll
   for (int g = 0; g < RB; ++g) xp[g] = x + (int64_t)min(g * 32 + (lane & 31), B - 1) * K + k0 * 16 + 8 * (lane >> 5);
-  // epilogue operands of this thread's 4 cells per row group (b = 32g + tid>>3, n = nb*32 + 4*(tid&7) ..+3), requested now
   const int en = nb * 32 + 4 * (tid & 7);
   float4 ebias = make_float4(0.f, 0.f, 0.f, 0.f), eres[RB];
 #pragma unroll
   for (int g = 0; g < RB; ++g) eres[g] = ebias;
-  if (tid < 256 && en + 3 < N) {
-    if (e.bias && ksplit == 1) ebias = *(const float4*)(e.bias + en);
-    if (e.residual && ksplit == 1) {
+  // epilogue operands of this thread's 4 cells per row group (b = 32g + tid>>3, n = nb*32 + 4*(tid&7) ..+3): requested
+  // together with the fragments (after them: the weights are the long pole)
+  auto prefetch_epilogue = [&]() {
+    if (tid < 256 && en + 3 < N) {
+      if (e.bias && ksplit == 1) ebias = *(const float4*)(e.bias + en);
+      if (e.residual && ksplit == 1) {
 #pragma unroll
-      for (int g = 0; g < RB; ++g) eres[g] = *(const float4*)(e.residual + (int64_t)min(g * 32 + (tid >> 3), B - 1) * e.ldc + en);
+        for (int g = 0; g < RB; ++g) eres[g] = *(const float4*)(e.residual + (int64_t)min(g * 32 + (tid >> 3), B - 1) * e.ldc + en);
+      }
     }
-  }
+  };
   f32x16 acc[RB];
 #pragma unroll
   for (int g = 0; g < RB; ++g)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[g][j] = 0.f;
-  for (int i0 = 0; i0 < steps; i0 += U) {
+  if constexpr (ONE) {
     u32x4 w[U], xv[RB][U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = min(i0 + u, steps - 1);  // clamped and unconditional: nothing branches around a load
-      w[u] = wp[(int64_t)i * 64];
+      const int i = min(u, steps - 1);  // clamped and unconditional: nothing branches around a load
+      if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64); else w[u] = wp[(int64_t)i * 64];
 #pragma unroll
       for (int g = 0; g < RB; ++g) xv[g][u] = *(const u32x4*)(xp[g] + i * 16);
     }
+    prefetch_epilogue();
+    __builtin_amdgcn_sched_barrier(0);  // every load is issued before the first MFMA waits: one round trip
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (i0 + u < steps) {
+      if (u < steps) {
 #pragma unroll
         for (int g = 0; g < RB; ++g)
           acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g], 0, 0, 0);
       }
+  } else {
+    prefetch_epilogue();
+    for (int i0 = 0; i0 < steps; i0 += U) {
+      u32x4 w[U], xv[RB][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u, steps - 1);
+        if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64); else w[u] = wp[(int64_t)i * 64];
+#pragma unroll
+        for (int g = 0; g < RB; ++g) xv[g][u] = *(const u32x4*)(xp[g] + i * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + u < steps) {
+#pragma unroll
+          for (int g = 0; g < RB; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g], 0, 0, 0);
+        }
+    }
   }
   // D: col = lane & 31 = batch row b, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) = output n
 #pragma unroll
@@ -215,15 +251,19 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
   if (ks_per % (nw * ksplit) != 0) return false;
   const int steps = ks_per / (nw * ksplit);
   dim3 grid(n_blocks, ksplit);
-#define TTASR_SKINNY(NW_, RB_, U_) \
-  hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride)
+#define TTASR_SKINNY(NW_, RB_, U_, ONE_)                                                                                              \
+  do {                                                                                                                                \
+    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride); \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride); \
+  } while (0)
 #define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
   do {                                                                             \
-    if (steps <= 2 && UMAX_ >= 2) TTASR_SKINNY(NW_, RB_, 2);                       \
-    else if (steps <= 4 && UMAX_ >= 4) TTASR_SKINNY(NW_, RB_, 4);                  \
-    else if (steps <= 5 || UMAX_ == 5) TTASR_SKINNY(NW_, RB_, 5);                  \
-    else if (steps <= 8 || UMAX_ == 8) TTASR_SKINNY(NW_, RB_, 8);                  \
-    else TTASR_SKINNY(NW_, RB_, 10);                                               \
+    if (steps <= 2 && UMAX_ >= 2) TTASR_SKINNY(NW_, RB_, 2, true);                 \
+    else if (steps <= 4 && UMAX_ >= 4) TTASR_SKINNY(NW_, RB_, 4, true);            \
+    else if (steps <= 5) TTASR_SKINNY(NW_, RB_, 5, true);                          \
+    else if (steps <= 8 && UMAX_ >= 8) TTASR_SKINNY(NW_, RB_, 8, true);            \
+    else if (steps <= UMAX_) TTASR_SKINNY(NW_, RB_, UMAX_, true);                  \
+    else TTASR_SKINNY(NW_, RB_, UMAX_, false);                                     \
   } while (0)
   if (rb == 1) {
     if (nw == 16) TTASR_SKINNY_U(16, 1, 10); else if (nw == 8) TTASR_SKINNY_U(8, 1, 10); else TTASR_SKINNY_U(4, 1, 10);

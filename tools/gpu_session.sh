@@ -1,12 +1,9 @@
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2c; mkdir -p $O
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"
-tail -8 $O/pytest.log
-timeout 600 python tools/decode_variants.py --variants auto,dual,qkv2 > $O/variants.jsonl 2> $O/variants.err; echo "variants rc=$?"
+O=gpurun_out/r2g; mkdir -p $O
+./tools/microbench/bin/skinny_bench2 > $O/skinny.txt 2>&1; cat $O/skinny.txt
+./tools/microbench/bin/layer_bench2 -1 > $O/layer.txt 2>&1; cat $O/layer.txt
+timeout 600 python tools/decode_variants.py --variants auto,w_nt > $O/variants.jsonl 2> $O/variants.err; echo "variants rc=$?"
 cat $O/variants.jsonl; tail -3 $O/variants.err
-timeout 900 python bench.py --cpu-full --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-cat $O/bench.json; tail -5 $O/bench.err
-cp profiles/cpu_baseline_full.json profiles/bench_tokens_crc.json $O/ 2>/dev/null
-timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_g2.json 2> $O/bench_g2.err; echo "bench2 rc=$?"
-cat $O/bench_g2.json; tail -5 $O/bench_g2.err
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"
+tail -4 $O/pytest.log
