@@ -93,6 +93,9 @@ bool gemm_bf16_v3_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
+// x += delta (the T-typed output of the preceding out-proj / fc2 GEMM), then LayerNorm(x) -> out; delta may alias out
+template <typename T>
+void launch_layernorm_add(float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
 // decode-step LayerNorm, one workgroup per row (kernels_misc.hip), that first completes the residual row:
 //   slab form:  x_out[row] = x[row] + bias + slab[0][row] + ... + slab[n_slab-1][row]   (fixed order, no atomics)
 //   embed form (tok != nullptr): x_out[row] = emb[tok[row]] + pos[*step]

@@ -97,6 +97,7 @@ struct ttasr_ctx {
   int ks_want[4] = {0, 0, 0, 0};  // TTASR_KS=d,q,qkv,fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
   int gemm_force = 0;         // TTASR_GEMM=v1|v2|v3 (A/B testing of the encoder GEMM kernels)
   bool no_flash = false;      // TTASR_NO_FLASH
+  bool enc_res_epilogue = false;  // TTASR_ENC_RES_EPI: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
   int max_new_alloc = 0, max_prompt_alloc = 0;
@@ -426,20 +427,38 @@ int run_encoder(ttasr_ctx* c, int B) {
     gemm<T>(c, g);
   }
   const int R = B * T_;
+  // bf16 mode: the out-proj / fc2 GEMMs write their result (bias added) as a T "delta" into the h buffer (dead at that
+  // point: its consumer GEMM has run) with the plain wide-store epilogue, and the LayerNorm that follows adds it to the
+  // f32 residual stream while normalising (kernels_misc.hip layernorm_kernel ADD).  The f32 residual read-modify-write in
+  // those GEMMs' epilogues - exposed at one workgroup per CU - was what held out-proj at 0.66 PF/s.
+  // f32 parity mode keeps the residual epilogue.
+  const bool delta = sizeof(T) == 2 && !c->force_basic && !c->enc_res_epilogue;
+  bool pending = false;  // a delta sits in h and has not been added to x yet
+  auto ln = [&](const float* g_, const float* b_, void* out) {
+    if (pending) launch_layernorm_add<T>(c->x, (const T*)c->h, g_, b_, (T*)out, R, d, s);
+    else launch_layernorm<T>(c->x, g_, b_, (T*)out, R, d, s);
+    pending = false;
+  };
+  auto residual_gemm = [&](const void* A, const void* W, const float* bias, int K) {
+    GemmArgs g = lin_args<T>(A, W, R, d, K); g.epi.bias = bias;
+    if (delta) { g.epi.out_t = c->h; pending = true; }
+    else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
+    gemm<T>(c, g);
+  };
   for (int l = 0; l < c->cfg.enc_layers; ++l) {
     const EncLayerW& L = c->enc[l];
-    launch_layernorm<T>(c->x, L.ln1g, L.ln1b, (T*)c->h, R, d, s);
+    ln(L.ln1g, L.ln1b, c->h);
     { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
     if (sizeof(T) == 2 && !c->force_basic && !c->no_flash)
       launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
     else
       launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
-    { GemmArgs g = lin_args<T>(c->att, L.wo, R, d, d); g.epi.bias = L.bo; g.epi.residual = c->x; g.epi.out_f32 = c->x; gemm<T>(c, g); }
-    launch_layernorm<T>(c->x, L.ln2g, L.ln2b, (T*)c->h, R, d, s);
+    residual_gemm(c->att, L.wo, L.bo, d);
+    ln(L.ln2g, L.ln2b, c->h);
     { GemmArgs g = lin_args<T>(c->h, L.w1, R, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->mid; gemm<T>(c, g); }
-    { GemmArgs g = lin_args<T>(c->mid, L.w2, R, d, ffn); g.epi.bias = L.b2; g.epi.residual = c->x; g.epi.out_f32 = c->x; gemm<T>(c, g); }
+    residual_gemm(c->mid, L.w2, L.b2, ffn);
   }
-  launch_layernorm<T>(c->x, c->elnf_g, c->elnf_b, (T*)c->enc_out, R, d, s);
+  ln(c->elnf_g, c->elnf_b, c->enc_out);
   hipEventRecord(c->ev[3], s);
   run_cross_kv<T>(c, B);
   hipEventRecord(c->ev[4], s);
@@ -786,6 +805,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
 #endif
   if (const char* v = getenv("TTASR_KS")) sscanf(v, "%d,%d,%d,%d", &c->ks_want[0], &c->ks_want[1], &c->ks_want[2], &c->ks_want[3]);
   c->no_flash = getenv("TTASR_NO_FLASH") != nullptr;
+  c->enc_res_epilogue = getenv("TTASR_ENC_RES_EPI") != nullptr;
   if (const char* v = getenv("TTASR_GEMM")) c->gemm_force = (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0;
   if (const char* v = getenv("TTASR_XATTN")) g_xattn_variant = atoi(v);
   // nontemporal weight loads: the 1.8 GB of decoder weights a step streams can never stay cached (measured -1 % per step)
@@ -1567,14 +1587,18 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       bytes = ((double)B * T_ * 4 * d + 3 * d * d) * e; flops = 2.0 * B * T_ * d * 3 * d;
     } else if (k == "enc_gemm_out") {
       GemmArgs g; g.A = c->att; g.W = c->enc[0].wo; g.M = B * c->T; g.N = c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
-      g.epi.ldc = c->d; g.epi.bias = c->enc[0].bo; g.epi.residual = c->x; g.epi.out_f32 = c->x;
+      g.epi.ldc = c->d; g.epi.bias = c->enc[0].bo;
+      const bool delta = c->bf16 && !c->force_basic && !c->enc_res_epilogue;  // the epilogue run_encoder uses
+      if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
       if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
-      bytes = ((double)B * T_ * d + d * d) * e + 8.0 * B * T_ * d; flops = 2.0 * B * T_ * d * d;
+      bytes = ((double)B * T_ * d + d * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * d;
     } else if (k == "enc_gemm_fc2") {
       GemmArgs g; g.A = c->mid; g.W = c->enc[0].w2; g.M = B * c->T; g.N = c->d; g.K = c->ffn; g.lda = c->ffn; g.ldw = c->ffn;
-      g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2; g.epi.residual = c->x; g.epi.out_f32 = c->x;
+      g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2;
+      const bool delta = c->bf16 && !c->force_basic && !c->enc_res_epilogue;
+      if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
       if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
-      bytes = ((double)B * T_ * ffn + ffn * d) * e + 8.0 * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
+      bytes = ((double)B * T_ * ffn + ffn * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
       if (c->bf16) {
         if (!c->force_basic && !c->no_flash) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);

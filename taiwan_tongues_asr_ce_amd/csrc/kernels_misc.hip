@@ -144,10 +144,15 @@ template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int,
 // registers (d <= 1280), then mean and the two-pass variance (as the oracle) come from registers.
 // HBM-bound: rows*d*(4 + sizeof(T)) bytes.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NV>  // NV = float4 per lane kept in registers: d <= 256 * NV
+// ADD (encoder, bf16 mode): the row is first completed as x += delta, where delta is the T-typed output of the
+// out-proj / fc2 GEMM that precedes the LayerNorm (bias already added), and written back to the f32 residual stream.
+// Moving the residual add out of those GEMMs' epilogues (a 492 MB f32 read-modify-write per GEMM at B = 32, exposed at one
+// workgroup per CU) into this HBM-streaming kernel lets them run the plain "bias -> T" epilogue.  delta may alias `out`
+// (each lane reads its delta chunks before it writes the same positions of the output).
+template <typename T, int NV, bool ADD>  // NV = float4 per lane kept in registers: d <= 256 * NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, T* __restrict__ out, int rows,
-                                                        int d) {
+                                                        const float* __restrict__ beta, T* out, int rows, int d,
+                                                        const T* delta, float* __restrict__ x_out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float4* xr = (const float4*)(x + (int64_t)row * d);
@@ -161,6 +166,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     v[j] = xr[i];
     gm[j] = ((const float4*)gamma)[i];
     bt[j] = ((const float4*)beta)[i];
+  }
+  if constexpr (ADD) {
+    float4 dl[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = min(lane + 64 * j, nv - 1);
+      if constexpr (sizeof(T) == 4) {
+        dl[j] = ((const float4*)(delta + (int64_t)row * d))[i];
+      } else {
+        const uint2 t = ((const uint2*)(delta + (int64_t)row * d))[i];
+        dl[j] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                            __uint_as_float(t.y & 0xffff0000u));
+      }
+    }
+    float4* xo = (float4*)(x_out + (int64_t)row * d);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      v[j].x += dl[j].x; v[j].y += dl[j].y; v[j].z += dl[j].z; v[j].w += dl[j].w;
+      if (lane + 64 * j < nv) xo[lane + 64 * j] = v[j];
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -196,15 +221,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
 }
+template <typename T, bool ADD>
+static void launch_layernorm_impl(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const T* delta,
+                                  float* x_out, hipStream_t s) {
+  dim3 grid((rows + 3) / 4), block(256);
+  if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+  else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+  else if (d <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+  else hipLaunchKernelGGL((layernorm_kernel<T, 5, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+}
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
-  dim3 grid((rows + 3) / 4), block(256);
-  if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, x, gamma, beta, out, rows, d);
-  else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, x, gamma, beta, out, rows, d);
-  else if (d <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, x, gamma, beta, out, rows, d);
-  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, x, gamma, beta, out, rows, d);
-  else hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, x, gamma, beta, out, rows, d);
+  launch_layernorm_impl<T, false>(x, gamma, beta, out, rows, d, nullptr, nullptr, s);
 }
+template <typename T>
+void launch_layernorm_add(float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
+  launch_layernorm_impl<T, true>(x, gamma, beta, out, rows, d, delta, x, s);
+}
+template void launch_layernorm_add<float>(float*, const float*, const float*, const float*, float*, int, int, hipStream_t);
+template void launch_layernorm_add<bf16_t>(float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // Decode-step LayerNorm (rows <= 128): one WORKGROUP per row, one float4 per thread, so the few rows of a decode
 // step spread over as many CUs as there are rows and every thread has a single round trip of (4 + n_slab)
