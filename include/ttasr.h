@@ -106,6 +106,18 @@ int ttasr_finalize_weights(ttasr_ctx* ctx);
  * it also receives float32 [B][n_mels][2*n_audio_ctx]. */
 int ttasr_log_mel(ttasr_ctx* ctx, const float* pcm, int64_t pcm_stride, const int64_t* n_samples_host, int32_t B,
                   int32_t pcm_on_device, float* out_mel_host);
+/* File-level form (faster-whisper computes the features of the WHOLE recording once and the 30-s window loop slices
+ * them: generate_segments, called from WhisperModel.transcribe at asr_core.py:159-167): B windows, window b belonging to
+ * the recording file_pcm_of_host[b][0..file_samples_of_host[b]) (the same pointer for windows of one file; different files
+ * when several files advance in lock step) and starting at its frame seek_frames_host[b] (10-ms frames).  Each window's
+ * frames are those of the whole-file STFT (true neighbour samples across window boundaries, reflection only at the ends
+ * of the file), frames beyond the end of the recording are 0 in feature space (pad_or_trim of the feature slice), and the
+ * dynamic-range floor is max - 8 of floor_max_host[b] when given (the caller passes the whole-file maximum, obtained from
+ * a first pass with out_window_max_host) instead of the window's own maximum.  out_window_max_host (optional) receives
+ * each window's log10-mel maximum over its valid frames.  Result resident for ttasr_encode like ttasr_log_mel. */
+int ttasr_log_mel_windows(ttasr_ctx* ctx, const float* const* file_pcm_of_host, const int64_t* file_samples_of_host,
+                          const int64_t* seek_frames_host, int32_t B, const float* floor_max_host, float* out_window_max_host,
+                          float* out_mel_host);
 /* Test hook: place a caller-computed mel [B][n_mels][2*n_audio_ctx] as the encoder input. */
 int ttasr_set_mel(ttasr_ctx* ctx, const float* mel_host, int32_t B);
 

@@ -276,6 +276,38 @@ def golden_bf16():
     np.savez_compressed(os.path.join(OUT, "tiny_bf16.npz"), **out)
 
 
+def golden_beam():
+    """Golden set G6: HF `generate(num_beams=5)` on the seeded tiny model (2 clips, 10 new tokens, the default suppress list,
+    with and without the timestamp rules).  No hypothesis reaches <|endoftext|> in this regime, so what it pins is the
+    evolution of the live beams and the final choice (highest cumulative log-probability); HF takes log_softmax BEFORE
+    masking (no renormalisation over the allowed tokens), openai-whisper / CTranslate2 after, hence `avg_score` is
+    compared with a tolerance and the finished-pool logic is pinned by the known-answer test in tests/."""
+    from transformers import LogitsProcessorList
+    from transformers.modeling_outputs import BaseModelOutput
+    dims = PRESETS["tiny"]
+    model, st = hf_model(dims)
+    model.generation_config.suppress_tokens = None
+    model.generation_config.begin_suppress_tokens = None
+    fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
+    pcm = [synth.noise_clip(0), synth.tonal_clip(1)]
+    mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
+    enc = model.model.encoder(torch.from_numpy(mel)).last_hidden_state
+    suppress = sorted(set(list(NON_SPEECH_TOKENS_MULTI) + [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]))
+    out = dict(suppress=np.array(suppress), begin_suppress=np.array([220, st.eot]), beam=np.array(5), n_new=np.array(10))
+    for tag, prompt, ts in (("nots", [st.sot, st.lang_zh, st.transcribe, st.no_timestamps], False),
+                            ("ts", [st.sot, st.lang_zh, st.transcribe], True)):
+        procs = LogitsProcessorList(hf_processors(st, len(prompt), ts, suppress, [220, st.eot]))
+        r = model.generate(encoder_outputs=BaseModelOutput(last_hidden_state=enc), decoder_input_ids=torch.tensor([prompt] * 2),
+                           num_beams=5, do_sample=False, max_new_tokens=10, length_penalty=1.0, early_stopping=False,
+                           logits_processor=procs, return_dict_in_generate=True, output_scores=True, eos_token_id=st.eot,
+                           pad_token_id=st.eot)
+        out[f"{tag}_prompt"] = np.array(prompt)
+        out[f"{tag}_tokens"] = r.sequences[:, len(prompt):].numpy()
+        out[f"{tag}_avg_score"] = r.sequences_scores.numpy()
+        print("beam", tag, r.sequences[:, len(prompt):].tolist(), r.sequences_scores.tolist())
+    np.savez_compressed(os.path.join(OUT, "beam_hf.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     golden_mel()
@@ -284,3 +316,4 @@ if __name__ == "__main__":
     golden_tiny()
     golden_align()
     golden_bf16()
+    golden_beam()

@@ -103,6 +103,23 @@ def log_mel(pcm: np.ndarray, n_mels: int, n_samples: int = 480000, n_fft: int = 
     return np.ascontiguousarray(logm.T).astype(np.float32)
 
 
+def log_mel_file(pcm: np.ndarray, n_mels: int) -> np.ndarray:
+    """Features of a WHOLE recording, f32[n_mels, len(pcm) // 160]: log_mel without the pad / trim to one window, i.e.
+    what WhisperFeatureExtractor(..., truncation=False, padding="longest") returns and what faster-whisper computes once per
+    file before its 30-s window loop (reflection only at the two ends of the file, ONE dynamic-range floor for the file)."""
+    return log_mel(pcm, n_mels, n_samples=len(pcm))
+
+
+def file_window(features: np.ndarray, seek: int, n_frames: int = 3000) -> np.ndarray:
+    """The encoder input of the window that starts at frame `seek`: features[:, seek:seek + n_frames], zero-padded in
+    FEATURE space when the recording ends inside the window ([HF] generation_whisper.py long-form loop;
+    faster-whisper pad_or_trim)."""
+    seg = features[:, seek:seek + n_frames]
+    out = np.zeros((features.shape[0], n_frames), dtype=np.float32)
+    out[:, :seg.shape[1]] = seg
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------------------

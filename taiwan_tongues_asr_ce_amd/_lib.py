@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libttasr.so")
 # every symbol include/ttasr.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "ttasr_create", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
-    "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
+    "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_log_mel_windows", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
     "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
     "ttasr_phase_ms", "ttasr_bench_kernel", "ttasr_sync",
 ]
@@ -67,6 +67,7 @@ def load() -> C.CDLL:
     lib.ttasr_load_tensor_device.argtypes = [vp, C.c_char_p, vp, i32, i64p, i32]
     lib.ttasr_finalize_weights.argtypes = [vp]
     lib.ttasr_log_mel.argtypes = [vp, vp, i64, i64p, i32, i32, vp]
+    lib.ttasr_log_mel_windows.argtypes = [vp, C.POINTER(vp), i64p, i64p, i32, vp, vp, vp]
     lib.ttasr_set_mel.argtypes = [vp, vp, i32]
     lib.ttasr_encode.argtypes = [vp, i32, vp]
     lib.ttasr_set_encoder_output.argtypes = [vp, vp, i32]

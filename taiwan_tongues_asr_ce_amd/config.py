@@ -57,6 +57,9 @@ PRESETS: Dict[str, WhisperDims] = {
     "medium": WhisperDims("medium", 80, 1500, 1024, 16, 4096, 24, 24, 51865),
     "large-v3": WhisperDims("large-v3", 128, 1500, 1280, 20, 5120, 32, 32, 51866),
     "large-v3-turbo": WhisperDims("large-v3-turbo", 128, 1500, 1280, 20, 5120, 32, 4, 51866),
+    # large-v3 WIDTH at 2 + 2 layers: every kernel runs the benchmarked shapes while the CPU oracle stays affordable
+    # (used by the parity tests of configs C3-C5, e.g. WhisperModel("synthetic:large-v3-w2"))
+    "large-v3-w2": WhisperDims("large-v3-w2", 128, 1500, 1280, 20, 5120, 2, 2, 51866),
 }
 
 

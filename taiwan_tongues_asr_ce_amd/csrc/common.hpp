@@ -132,13 +132,16 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
                         float* slab = nullptr, int64_t slab_stride = 0);
 int gemm_skinny_ksplit(int B, int N, int K, int want);
 // mel
+// geom_dev (optional): int64 [B][3] = {lead, reflect_end, valid_frames} per clip - window-of-a-file geometry, kernels_misc.hip
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
                 const float* filters /*[201][n_mels]*/, const float* dft_cos, const float* dft_sin /*[400]*/,
                 const float* window /*[400]*/, float* logmel /*[B][n_mels][n_frames]*/, unsigned* clip_max /*[B]*/,
-                hipStream_t s);
+                hipStream_t s, const int64_t* geom_dev = nullptr);
+unsigned mel_max_to_ordered(float v);   // clip_max holds the per-clip maximum as an order-preserving unsigned
+float mel_max_from_ordered(unsigned u);
 template <typename T>
 void launch_mel_finish(float* logmel, const unsigned* clip_max, T* mel_t /*[B][n_frames+2][n_mels]*/, int B, int n_mels,
-                       int n_frames, hipStream_t s);
+                       int n_frames, hipStream_t s, const int64_t* geom_dev = nullptr);
 template <typename T>
 void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s);
 

@@ -76,7 +76,7 @@ struct ttasr_ctx {
   float *filters = nullptr, *dcos = nullptr, *dsin = nullptr, *window = nullptr;
 
   // workspaces
-  float* pcm_dev = nullptr; int64_t* nsamp_dev = nullptr; unsigned* clip_max = nullptr;
+  float* pcm_dev = nullptr; int64_t* nsamp_dev = nullptr; unsigned* clip_max = nullptr; int64_t* mel_geom = nullptr;
   float* mel = nullptr; void* mel_t = nullptr; void* c1 = nullptr;
   float* x = nullptr; void *h = nullptr, *qkv = nullptr, *att = nullptr, *mid = nullptr, *enc_out = nullptr;
   void* xkv = nullptr; int64_t xkv_layer_elems = 0, xkv_which_elems = 0;
@@ -297,7 +297,8 @@ int build_weights(ttasr_ctx* c) {
 
 int build_workspaces(ttasr_ctx* c) {
   const int64_t B = c->maxB, T = c->T, F = c->F, d = c->d, M = c->M, H = c->H;
-  TRY(dalloc(c, &c->pcm_dev, (size_t)B * c->n_samples * 4));
+  TRY(dalloc(c, &c->pcm_dev, (size_t)B * (c->n_samples + 512) * 4));  // + context samples of file windows
+  TRY(dalloc(c, &c->mel_geom, (size_t)B * 3 * 8));
   TRY(dalloc(c, &c->nsamp_dev, (size_t)B * 8));
   TRY(dalloc(c, &c->clip_max, (size_t)B * 4));
   TRY(dalloc(c, &c->mel, (size_t)B * M * F * 4));
@@ -942,6 +943,58 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
   hipEventRecord(c->ev[1], s);
   if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  HIPCHK(c, hipGetLastError());
+  hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);
+  c->B_mel = B;
+  return TTASR_OK;
+  });
+}
+
+int ttasr_log_mel_windows(ttasr_ctx* c, const float* const* file_pcm_of, const int64_t* file_samples_of, const int64_t* seek_frames,
+                          int32_t B, const float* floor_max, float* out_window_max, float* out_mel) {
+  return guarded(c, [&]() -> int {
+  if (!c) return TTASR_E_INVALID;
+  if (B < 1 || B > c->maxB) return fail(c, TTASR_E_INVALID, "batch %d outside [1, %d]", B, c->maxB);
+  if (!file_pcm_of || !file_samples_of || !seek_frames) return fail(c, TTASR_E_INVALID, "NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int64_t stride = c->n_samples + 512;
+  std::vector<int64_t> ns(B), geom((size_t)3 * B);
+  hipEventRecord(c->ev[0], s);
+  for (int b = 0; b < B; ++b) {
+    const float* file_pcm = file_pcm_of[b];
+    const int64_t file_samples = file_samples_of[b];
+    if (!file_pcm || file_samples < 0) return fail(c, TTASR_E_INVALID, "window %d: recording is NULL / negative length", b);
+    const int64_t file_frames = file_samples / 160;   // the whole-file STFT drops its last frame (HF feature extractor :154)
+    const int64_t seek = seek_frames[b];
+    if (seek < 0 || seek > file_frames) return fail(c, TTASR_E_INVALID, "seek_frames[%d]=%lld outside the recording (%lld frames)", b, (long long)seek, (long long)file_frames);
+    const int64_t start = seek * 160, lead = std::min<int64_t>(200, start);
+    const int64_t avail = std::min<int64_t>(file_samples - (start - lead), lead + c->n_samples + 200);  // samples from x[0]
+    ns[b] = std::max<int64_t>(avail, 0);
+    geom[3 * b] = lead;
+    // reflect where the FILE ends if that is inside the span this window's frames touch; otherwise never
+    geom[3 * b + 1] = (file_samples - (start - lead) < lead + c->n_samples + 200) ? file_samples - (start - lead) : ((int64_t)1 << 40);
+    geom[3 * b + 2] = std::min<int64_t>(c->F, file_frames - seek);
+    if (ns[b] > 0) HIPCHK(c, hipMemcpyAsync(c->pcm_dev + (int64_t)b * stride, file_pcm + (start - lead), ns[b] * 4, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipMemcpyAsync(c->mel_geom, geom.data(), (size_t)B * 24, hipMemcpyHostToDevice, s));
+  launch_mel(c->pcm_dev, stride, c->nsamp_dev, B, c->M, c->F, c->filters, c->dcos, c->dsin, c->window, c->mel, c->clip_max, s, c->mel_geom);
+  std::vector<unsigned> mx(B);
+  if (out_window_max) {
+    HIPCHK(c, hipMemcpyAsync(mx.data(), c->clip_max, B * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) out_window_max[b] = mel_max_from_ordered(mx[b]);
+  }
+  if (floor_max) {  // the whole-file maximum decides the dynamic-range floor of every window
+    for (int b = 0; b < B; ++b) mx[b] = mel_max_to_ordered(floor_max[b]);
+    HIPCHK(c, hipMemcpyAsync(c->clip_max, mx.data(), B * 4, hipMemcpyHostToDevice, s));
+  }
+  if (c->bf16) launch_mel_finish<bf16_t>(c->mel, c->clip_max, (bf16_t*)c->mel_t, B, c->M, c->F, s, c->mel_geom);
+  else launch_mel_finish<float>(c->mel, c->clip_max, (float*)c->mel_t, B, c->M, c->F, s, c->mel_geom);
+  hipEventRecord(c->ev[1], s);
+  if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));  // mx / ns / geom are stack temporaries
   HIPCHK(c, hipGetLastError());
   hipEventElapsedTime(&c->phase_ms[0], c->ev[0], c->ev[1]);
   c->B_mel = B;

@@ -1,5 +1,6 @@
 // Log-mel front end, LayerNorm and small utility kernels.
 #include "common.hpp"
+#include <cstring>
 
 // ------------------------------------------------------------------------------------------------
 // a5: log-mel.  Restates FeatureExtractor.__call__ of faster-whisper == HF feature_extraction_whisper.py
@@ -21,23 +22,33 @@ __device__ __forceinline__ float ord2f(unsigned u) {
 constexpr int MEL_F = 8;             // frames per workgroup
 constexpr int MEL_SPAN = 160 * (MEL_F - 1) + 400;  // 1520
 
+// Window geometry (geom != nullptr; file-level transcription): clip b is a 30-s WINDOW of a longer recording.  geom[b] =
+// {lead, reflect_end, valid_frames}: x points `lead` samples (0 at the start of the file, else 200) before the centre of
+// frame 0, so interior windows see their true neighbour samples instead of a reflection; the signal is reflected at
+// sample index reflect_end (the end of the FILE when it falls inside this window's span, as a whole-file STFT does) and
+// frames >= valid_frames lie beyond the recording: the finishing kernel sets them to 0 in feature space, exactly what
+// faster-whisper's pad_or_trim(features[:, seek:seek + 3000]) and HF's long-form loop feed the encoder.  geom == nullptr
+// is the single-clip form (pad / trim the clip to one window, reflect at the window end), unchanged.
 __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ pcm, int64_t pcm_stride,
                                                   const int64_t* __restrict__ n_samples, int n_mels, int n_frames,
                                                   const float* __restrict__ filters, const float* __restrict__ dcos,
                                                   const float* __restrict__ dsin, const float* __restrict__ window,
-                                                  float* __restrict__ logmel, unsigned* __restrict__ clip_max) {
+                                                  float* __restrict__ logmel, unsigned* __restrict__ clip_max,
+                                                  const int64_t* __restrict__ geom) {
   __shared__ float xs[MEL_SPAN];
   __shared__ float tc[400], tsn[400], win[400];
   __shared__ float pw[MEL_F][208];
   __shared__ float red[4];
   const int b = blockIdx.y, f0 = blockIdx.x * MEL_F, tid = threadIdx.x;
-  const int64_t n_valid = min((int64_t)n_frames * 160, n_samples[b]);
-  const int64_t total = (int64_t)n_frames * 160;  // window length the clip is padded / trimmed to
+  const int64_t lead = geom ? geom[3 * b] : 0;
+  const int64_t total = geom ? geom[3 * b + 1] : (int64_t)n_frames * 160;  // where the signal is reflected
+  const int valid_frames = geom ? (int)geom[3 * b + 2] : n_frames;
+  const int64_t n_valid = geom ? n_samples[b] : min((int64_t)n_frames * 160, n_samples[b]);
   const float* x = pcm + (int64_t)b * pcm_stride;
   for (int i = tid; i < 400; i += 256) { tc[i] = dcos[i]; tsn[i] = dsin[i]; win[i] = window[i]; }
   // sample index of xs[i] in the padded clip: s = f0*160 - 200 + i, reflected at both ends
   for (int i = tid; i < MEL_SPAN; i += 256) {
-    int64_t sidx = (int64_t)f0 * 160 - 200 + i;
+    int64_t sidx = lead + (int64_t)f0 * 160 - 200 + i;
     if (sidx < 0) sidx = -sidx;
     if (sidx >= total) sidx = 2 * (total - 1) - sidx;
     xs[i] = (sidx >= 0 && sidx < n_valid) ? x[sidx] : 0.0f;
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ pcm,
       for (int k = 0; k < 201; ++k) acc = fmaf(pw[f][k], filters[k * n_mels + m], acc);
       float l = log10f(fmaxf(acc, 1e-10f));
       logmel[((int64_t)b * n_mels + m) * n_frames + f0 + f] = l;
-      lmax = fmaxf(lmax, l);
+      if (f0 + f < valid_frames) lmax = fmaxf(lmax, l);  // the maximum is taken over the recording, not over its padding
     }
   }
   lmax = wave_max(lmax);
@@ -82,29 +93,33 @@ __global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ pcm,
 
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
                 const float* filters, const float* dft_cos, const float* dft_sin, const float* window, float* logmel,
-                unsigned* clip_max, hipStream_t s) {
+                unsigned* clip_max, hipStream_t s, const int64_t* geom_dev) {
   hipMemsetAsync(clip_max, 0, sizeof(unsigned) * B, s);
   dim3 grid((n_frames + MEL_F - 1) / MEL_F, B);
   hipLaunchKernelGGL(mel_kernel, grid, dim3(256), 0, s, pcm, pcm_stride, n_samples_dev, n_mels, n_frames, filters,
-                     dft_cos, dft_sin, window, logmel, clip_max);
+                     dft_cos, dft_sin, window, logmel, clip_max, geom_dev);
 }
+unsigned mel_max_to_ordered(float v) { unsigned u; memcpy(&u, &v, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+float mel_max_from_ordered(unsigned u) { u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float v; memcpy(&v, &u, 4); return v; }
 
 // normalise in place ([B][M][F] f32, the API-visible layout) and write the encoder's input image:
 // time-major [B][F+2][M] in T with a zero row before and after each clip (conv padding, see engine).
 template <typename T>
 __global__ __launch_bounds__(256) void mel_finish_kernel(float* __restrict__ logmel, const unsigned* __restrict__ clip_max,
-                                                         T* __restrict__ mel_t, int n_mels, int n_frames, int normalise) {
+                                                         T* __restrict__ mel_t, int n_mels, int n_frames, int normalise,
+                                                         const int64_t* __restrict__ geom) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, f0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const float floor_v = normalise ? ord2f(clip_max[b]) - 8.0f : 0.f;
+  const int valid_frames = geom ? (int)geom[3 * b + 2] : n_frames;  // frames beyond the recording: 0 in feature space
   for (int r = ty; r < 32; r += 8) {
     int m = m0 + r, f = f0 + tx;
     if (m < n_mels && f < n_frames) {
       int64_t i = ((int64_t)b * n_mels + m) * n_frames + f;
       float v = logmel[i];
       if (normalise) {
-        v = (fmaxf(v, floor_v) + 4.0f) * 0.25f;
+        v = f < valid_frames ? (fmaxf(v, floor_v) + 4.0f) * 0.25f : 0.f;
         logmel[i] = v;
       }
       tile[r][tx] = v;
@@ -124,18 +139,19 @@ __global__ __launch_bounds__(256) void mel_finish_kernel(float* __restrict__ log
 }
 
 template <typename T>
-void launch_mel_finish(float* logmel, const unsigned* clip_max, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s) {
+void launch_mel_finish(float* logmel, const unsigned* clip_max, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s,
+                       const int64_t* geom_dev) {
   dim3 grid((n_frames + 31) / 32, (n_mels + 31) / 32, B);
-  hipLaunchKernelGGL(mel_finish_kernel<T>, grid, dim3(256), 0, s, logmel, clip_max, mel_t, n_mels, n_frames, 1);
+  hipLaunchKernelGGL(mel_finish_kernel<T>, grid, dim3(256), 0, s, logmel, clip_max, mel_t, n_mels, n_frames, 1, geom_dev);
 }
 template <typename T>
 void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_frames, hipStream_t s) {
   dim3 grid((n_frames + 31) / 32, (n_mels + 31) / 32, B);
   hipLaunchKernelGGL(mel_finish_kernel<T>, grid, dim3(256), 0, s, (float*)mel, (const unsigned*)nullptr, mel_t, n_mels,
-                     n_frames, 0);
+                     n_frames, 0, (const int64_t*)nullptr);
 }
-template void launch_mel_finish<float>(float*, const unsigned*, float*, int, int, int, hipStream_t);
-template void launch_mel_finish<bf16_t>(float*, const unsigned*, bf16_t*, int, int, int, hipStream_t);
+template void launch_mel_finish<float>(float*, const unsigned*, float*, int, int, int, hipStream_t, const int64_t*);
+template void launch_mel_finish<bf16_t>(float*, const unsigned*, bf16_t*, int, int, int, hipStream_t, const int64_t*);
 template void launch_mel_transpose<float>(const float*, float*, int, int, int, hipStream_t);
 template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
 

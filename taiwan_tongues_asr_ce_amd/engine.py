@@ -118,6 +118,28 @@ class Engine:
                                            _ptr(out) if want_output else None), "log_mel")
         return out
 
+    def log_mel_windows(self, audio, seeks: Sequence[int], floor_max: Optional[Sequence[float]] = None,
+                        want_output: bool = False, want_max: bool = False):
+        """Windows of recordings (ttasr_log_mel_windows): window b starts at 10-ms frame seeks[b] of `audio` (one float32
+        array = all windows belong to that recording) or of audio[b] (a sequence: one recording per window, several files in
+        lock step); frames are those of the whole-file STFT, frames past the end of the recording are 0 in feature space,
+        and the dynamic-range floor comes from floor_max[b] (the whole-file log-mel maximum) when given.
+        Returns (mel or None, per-window maxima or None)."""
+        sk = np.ascontiguousarray(seeks, dtype=np.int64)
+        B = len(sk)
+        files = [audio] * B if isinstance(audio, np.ndarray) else list(audio)
+        files = [np.ascontiguousarray(a, dtype=np.float32) for a in files]
+        ptrs = (C.c_void_p * B)(*[a.ctypes.data for a in files])
+        lens = np.asarray([len(a) for a in files], dtype=np.int64)
+        fm = None if floor_max is None else np.ascontiguousarray(floor_max, dtype=np.float32)
+        out = np.empty((B, self.dims.n_mels, 2 * self.audio_ctx), dtype=np.float32) if want_output else None
+        mx = np.empty(B, dtype=np.float32) if want_max else None
+        i64p = C.POINTER(C.c_int64)
+        self._check(self.lib.ttasr_log_mel_windows(self.h, ptrs, lens.ctypes.data_as(i64p), sk.ctypes.data_as(i64p), B,
+                                                   _ptr(fm) if fm is not None else None, _ptr(mx) if want_max else None,
+                                                   _ptr(out) if want_output else None), "log_mel_windows")
+        return out, mx
+
     def log_mel_device(self, dev_ptr: int, stride: int, n_samples: Sequence[int]):
         """PCM already resident in HBM (bench): dev_ptr = device address of float32 [B][stride]."""
         ns = np.asarray(n_samples, dtype=np.int64)

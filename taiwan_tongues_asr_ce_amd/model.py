@@ -160,7 +160,9 @@ def _read_hf_dir(path: str) -> Tuple[WhisperDims, Iterable[Tuple[str, np.ndarray
 
 class WhisperModel:
     def __init__(self, model_size_or_path: str, device: str = "auto", device_index: int = 0,
-                 compute_type: str = "default", max_batch: int = 8, **_unused):
+                 compute_type: str = "default", max_batch: int = 8, _engine_factory=None, **_unused):
+        """`_engine_factory` is a TEST seam only (tests/oracle_engine.py drives the host-side window loop with the CPU oracle
+        to pin it against HF long-form goldens without a GPU); the product always builds the HIP Engine."""
         if device not in ("cuda", "auto", "gpu", "hip"):
             raise RuntimeError(f"device={device!r}: this build has only the MI355X HIP path (no CPU fallback)")
         if compute_type not in _COMPUTE_ALIASES:
@@ -202,7 +204,7 @@ class WhisperModel:
             # 16-bit type is bfloat16 and it has no int8 path - say so instead of silently computing in another type
             warnings.warn(f"compute_type={compute_type!r} is not implemented by this engine: computing in bfloat16 "
                           "(bf16 weights and activations, f32 accumulation, LayerNorm and softmax)", stacklevel=2)
-        self.engine = Engine(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
+        self.engine = (_engine_factory or Engine)(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
         self.engine.load_weights(tensors)
         self.special = self.engine.special
         self.max_batch = max_batch
@@ -490,11 +492,27 @@ class WhisperModel:
         fs["seek"] += min(advance, win_frames) if advance > 0 else win_frames
         return out
 
+    def _file_feature_max(self, audio: np.ndarray) -> float:
+        """faster-whisper extracts the features of the whole (VAD-filtered) recording once, so the dynamic-range floor
+        `max - 8` is the FILE's, not the window's: a first pass over all windows (max_batch at a time; ~1 ms per 32 windows)
+        returns the per-window log-mel maxima, their maximum is handed to every window's feature call."""
+        n_frames = len(audio) // HOP
+        if n_frames <= 0:
+            return 0.0
+        seeks = list(range(0, n_frames, self.dims.n_frames))
+        best = -np.inf
+        for i in range(0, len(seeks), self.max_batch):
+            _, mx = self.engine.log_mel_windows(audio, seeks[i:i + self.max_batch], want_max=True)
+            best = max(best, float(np.max(mx)))
+        return best
+
     def _new_file_state(self, audio: np.ndarray, initial_prompt: Optional[str]) -> dict:
         prev: List[int] = []
         if initial_prompt:
             prev.extend(self.tokenizer.encode(" " + initial_prompt.strip()))
-        return dict(audio=audio, n_total=int(np.ceil(len(audio) / HOP)) if len(audio) else 0, prev=prev, prompt_reset=0,
+        # frames of the whole-file STFT: len // HOP (the feature extractor drops its last frame); a tail shorter than one hop
+        # still yields one (all-padding) window, as faster-whisper's 160 samples of end padding do
+        return dict(audio=audio, n_total=max(len(audio) // HOP, 1) if len(audio) else 0, prev=prev, prompt_reset=0,
                     seek=0, idx=0)
 
     def _params(self, language, task, condition, without_timestamps, max_new_tokens, no_speech_threshold, log_prob_threshold,
@@ -517,11 +535,13 @@ class WhisperModel:
                          log_prob_threshold, max_initial_timestamp, suppress_blank, beam_size, patience, temperatures, best_of,
                          compression_ratio_threshold, word_timestamps, hotwords, prefix)
         fs = self._new_file_state(audio, initial_prompt)
+        eng.set_audio_ctx(0)
+        file_max = self._file_feature_max(audio)   # before the first window: the floor is the recording's, not the window's
         while fs["seek"] < fs["n_total"]:
             seek = fs["seek"]
             win_frames = min(self.dims.n_frames, fs["n_total"] - seek)
             eng.set_audio_ctx(0)
-            eng.log_mel([audio[seek * HOP: seek * HOP + self.n_window]], want_output=False)
+            eng.log_mel_windows(audio, [seek], floor_max=[file_max])
             eng.encode(1)
             prompt, sot_index = self._prompt(p["lang_tok"], task, without_timestamps, fs["prev"][fs["prompt_reset"]:],
                                              p["hotwords_tokens"], p["prefix_tokens"] if seek == 0 else None)
@@ -556,6 +576,7 @@ class WhisperModel:
                 raise ValueError(f"audio must be mono float32 [n] @16 kHz, got shape {a.shape}")
             fs = self._new_file_state(np.ascontiguousarray(a, dtype=np.float32), initial_prompt)
             fs["segments"] = []
+            fs["file_max"] = self._file_feature_max(fs["audio"])   # whole-file dynamic-range floor, as `transcribe`
             files.append(fs)
         while True:
             active = [fs for fs in files if fs["seek"] < fs["n_total"]]
@@ -563,9 +584,9 @@ class WhisperModel:
                 break
             for g in range(0, len(active), per_pass):
                 group = active[g:g + per_pass]
-                chunks = [fs["audio"][fs["seek"] * HOP: fs["seek"] * HOP + self.n_window] for fs in group]
                 eng.set_audio_ctx(0)
-                eng.log_mel(chunks, want_output=False)
+                eng.log_mel_windows([fs["audio"] for fs in group], [fs["seek"] for fs in group],
+                                    floor_max=[fs["file_max"] for fs in group])
                 eng.encode(len(group))
                 prompts, sots = [], []
                 for fs in group:
@@ -582,11 +603,11 @@ class WhisperModel:
                     toks, avg_lp, ns, cr = first[i]
                     win_frames = min(self.dims.n_frames, fs["n_total"] - fs["seek"])
                     if temps[0] <= 0.0 and self._needs_fallback(avg_lp, ns, cr, p) and len(temps) > 1:
-                        redo.append((fs, prompts[i], sots[i], first[i], win_frames, chunks[i]))
+                        redo.append((fs, prompts[i], sots[i], first[i], win_frames))
                     else:
                         fs["segments"].extend(self._finish_window(fs, i, (temps[0], toks, avg_lp, ns, cr), win_frames, p))
-                for fs, pr, si, fst, win_frames, chunk in redo:   # rare: this window alone, through the whole ladder
-                    eng.log_mel([chunk], want_output=False)
+                for fs, pr, si, fst, win_frames in redo:   # rare: this window alone, through the whole ladder
+                    eng.log_mel_windows(fs["audio"], [fs["seek"]], floor_max=[fs["file_max"]])
                     eng.encode(1)
                     attempt = self._decode_with_fallback(pr, self._window_opts(len(pr), si, p), fs["seek"], p, first=fst)
                     fs["segments"].extend(self._finish_window(fs, 0, attempt, win_frames, p))

@@ -299,7 +299,8 @@ def test_hotwords_and_prefix_reach_the_engine(model):
     st = model.special
     dims = R.Dims(**PRESETS["tiny"].as_dict())
     W = R.to_torch(synth.state_dict(PRESETS["tiny"]))
-    enc = R.encoder_forward(torch.from_numpy(R.log_mel(audio, 80))[None], W, dims)
+    # a 12-s recording: the features of the recording, zero-padded in FEATURE space to one window (faster-whisper pad_or_trim)
+    enc = R.encoder_forward(torch.from_numpy(R.file_window(R.log_mel_file(audio, 80), 0))[None], W, dims)
     from taiwan_tongues_asr_ce_amd.engine import default_suppress
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=True)
