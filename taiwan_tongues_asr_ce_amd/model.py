@@ -444,8 +444,16 @@ class WhisperModel:
     def _window_opts(self, prompt_len: int, sot_index: int, p):
         st = self.special
         budget = min(p["max_new"], self.dims.n_text_ctx - prompt_len)
-        return self.engine.gen_opts(budget, timestamps=not p["without_timestamps"], sot_index=sot_index,
-                                    begin_suppress=[220, st.eot] if p["suppress_blank"] else [],
+        # the model directory's own lists win (CTranslate2 config.json "suppress_ids" / "suppress_ids_begin", what
+        # faster-whisper reads for suppress_tokens=[-1] / suppress_blank); otherwise the published defaults
+        cfg = self.ct2_config
+        sup = None
+        if cfg.get("suppress_ids"):
+            sup = sorted({int(t) for t in cfg["suppress_ids"] if 0 <= int(t) < self.dims.vocab} |
+                         {st.transcribe, st.translate, st.sot, st.sot_prev} | ({st.sot_lm} if st.sot_lm >= 0 else set()))
+        bsup = [int(t) for t in cfg["suppress_ids_begin"] if 0 <= int(t) < self.dims.vocab] if cfg.get("suppress_ids_begin") else [220, st.eot]
+        return self.engine.gen_opts(budget, timestamps=not p["without_timestamps"], sot_index=sot_index, suppress=sup,
+                                    begin_suppress=bsup if p["suppress_blank"] else [],
                                     max_initial_timestamp_index=int(round(p["max_initial_timestamp"] / 0.02)), check_interval=4)
 
     def _finish_window(self, fs: dict, clip_index: int, attempt, win_frames: int, p) -> List[Segment]:

@@ -49,6 +49,32 @@ def energy_speech_prob(audio: np.ndarray, window: int = WINDOW) -> np.ndarray:
     return (1.0 / (1.0 + np.exp(-(db - floor - 6.0) / 1.5))).astype(np.float32)
 
 
+def silero_speech_prob_fn(step: Callable[[np.ndarray, np.ndarray], "tuple[float, np.ndarray]"], context: int = 64,
+                          state_shape: Sequence[int] = (2, 1, 128)) -> Callable[[np.ndarray], np.ndarray]:
+    """Adapter for an operator-supplied Silero VAD network (the ONNX file faster-whisper ships; not available offline):
+    `step(frame, state) -> (speech_probability, new_state)` is ONE forward of the network, e.g.
+        lambda x, h: (lambda o: (float(o[0].squeeze()), o[1]))(session.run(None, {"input": x, "state": h, "sr": np.array(16000)}))
+    and the returned function is what `WhisperModel.vad_speech_prob_fn` / `vad_speech_prob_fn=` expect.  It drives the
+    network the way Silero's v5 graph is specified: 512-sample frames (32 ms), each prefixed with the last `context` = 64
+    samples of the previous frame (zeros before the first), float32 [1, 576]; the recurrent state ([2, 1, 128], zeros at
+    the start of a recording) is threaded from call to call; the last frame is zero-padded."""
+    def fn(audio: np.ndarray) -> np.ndarray:
+        audio = np.asarray(audio, dtype=np.float32)
+        n = int(np.ceil(len(audio) / WINDOW)) if len(audio) else 0
+        padded = np.zeros(n * WINDOW, dtype=np.float32)
+        padded[: len(audio)] = audio
+        state = np.zeros(tuple(state_shape), dtype=np.float32)
+        ctx = np.zeros(context, dtype=np.float32)
+        out = np.zeros(n, dtype=np.float32)
+        for i in range(n):
+            frame = padded[i * WINDOW:(i + 1) * WINDOW]
+            p, state = step(np.concatenate([ctx, frame])[None, :], state)
+            out[i] = float(p)
+            ctx = frame[-context:] if context else ctx
+        return out
+    return fn
+
+
 def get_speech_timestamps(audio: np.ndarray, options: Optional[VadOptions] = None,
                           speech_prob_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
                           sampling_rate: int = SAMPLING_RATE) -> List[Dict[str, int]]:

@@ -104,3 +104,25 @@ def test_old_binary_version_and_damage(tmp_path):
     ct2.write_model_bin(str(d / "model.bin"), {"x": data})
     with pytest.raises(ct2.CT2FormatError, match="no variable"):
         ct2.read_ct2_dir(str(d))
+
+
+def test_reader_against_the_independent_int8_writer(tmp_path):
+    """A full Whisper model written by tests/ct2_fixture_writer.py (no code shared with ct2.py: int8 linears with per-row
+    `_scale`, float16 elsewhere, aliased + quantised output projection, variables sorted by name) reads back to exactly the
+    de-quantised tensors, with the geometry inferred from the shapes alone."""
+    from ct2_fixture_writer import write_whisper_ct2_int8
+    hf = _hf()
+    expect = write_whisper_ct2_int8(str(tmp_path), hf, DIMS.n_heads, DIMS.enc_layers, DIMS.dec_layers,
+                                    config={"suppress_ids": [1, 2, 7], "suppress_ids_begin": [220, 50257], "alignment_heads": [[1, 0]]})
+    dims, tensors, cfg = ct2.read_ct2_dir(str(tmp_path))
+    assert (dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, dims.enc_layers, dims.dec_layers,
+            dims.vocab, dims.n_text_ctx) == (DIMS.n_mels, DIMS.n_audio_ctx, DIMS.d_model, DIMS.n_heads, DIMS.ffn_dim,
+                                             DIMS.enc_layers, DIMS.dec_layers, DIMS.vocab, DIMS.n_text_ctx)
+    got = dict(tensors)
+    assert set(got) == set(hf) == set(expect)
+    for k in hf:
+        assert got[k].dtype == np.float32 and got[k].shape == hf[k].shape, k
+        np.testing.assert_array_equal(got[k], expect[k], err_msg=k)                   # exactly the de-quantised values
+        err = np.abs(got[k] - hf[k]).max()
+        assert err <= np.abs(hf[k]).max() * (1.0 / 127 if hf[k].ndim == 2 else 2e-3) + 1e-6, (k, err)   # and close to the originals
+    assert cfg["alignment_heads"] == [[1, 0]]

@@ -82,3 +82,31 @@ def test_energy_stand_in_finds_the_burst():
     assert p[: n_loud - 1].min() > 0.9 and p[n_loud + 1:].max() < 0.1
     got = vad.get_speech_timestamps(clip, vad.VadOptions())
     assert len(got) == 1 and got[0]["start"] == 0 and abs(got[0]["end"] - (3 * 16000 + 6400)) <= W
+
+
+def test_silero_shaped_network_is_driven_frame_by_frame_with_context_and_state():
+    """The Silero network itself cannot be shipped (no weights offline): what is pinned is that a Silero-SHAPED stateful
+    callable is driven correctly - 512-sample frames prefixed by 64 context samples, float32 [1, 576], the recurrent state
+    [2, 1, 128] threaded through, the tail zero-padded - and that its probabilities reach the chunking rule."""
+    from taiwan_tongues_asr_ce_amd import vad
+    seen = []
+
+    def step(x, h):
+        assert x.shape == (1, 576) and x.dtype == np.float32 and h.shape == (2, 1, 128) and h.dtype == np.float32
+        seen.append((x.copy(), float(h[0, 0, 0])))
+        level = float(np.abs(x[0, 64:]).mean())
+        return (0.9 if level > 0.05 else 0.02), h + 1.0            # the "state" counts the calls
+
+    audio = np.zeros(16000 * 3 + 100, dtype=np.float32)
+    audio[16000:32000] = 0.3 * np.sin(np.arange(16000) * 0.2)
+    fn = vad.silero_speech_prob_fn(step)
+    probs = fn(audio)
+    n = int(np.ceil(len(audio) / 512))
+    assert probs.shape == (n,) and len(seen) == n
+    assert [h for _, h in seen] == [float(i) for i in range(n)]                    # state threaded call to call, zeros first
+    assert not seen[0][0][0, :64].any()                                            # no context before the first frame
+    for i in range(1, n):
+        np.testing.assert_array_equal(seen[i][0][0, :64], seen[i - 1][0][0, -64:])  # context = tail of the previous frame
+    assert not seen[-1][0][0, 64 + (len(audio) - (n - 1) * 512):].any()            # zero-padded tail
+    chunks = vad.get_speech_timestamps(audio, vad.VadOptions(min_silence_duration_ms=300, speech_pad_ms=0), fn)
+    assert len(chunks) == 1 and abs(chunks[0]["start"] - 16000) <= 512 and abs(chunks[0]["end"] - 32000) <= 1024
