@@ -375,13 +375,18 @@ def main():
             eng.bench_kernel(n, B, iters=10)
         gs = [eng.bench_kernel(n, B, iters=30) for n in names]
         enc_tf = sum(x["flops"] for x in gs) / (sum(x["ms"] for x in gs) * 1e-3) / 1e12
-        # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent)
+        # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent; static, like traffic)
         pmc_busy = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r1_k_pmc.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r2_pmc.json")) as f:
                 kk_ = json.load(f)["kernels"]
-            fr = [kk_["enc qkv GEMM (EPI 0)"]["mfma_busy_frac"], kk_["enc out-proj / fc2 GEMM + f32 residual (EPI 18)"]["mfma_busy_frac"],
-                  kk_["enc fc1 GEMM + GELU (EPI 1)"]["mfma_busy_frac"], kk_["enc out-proj / fc2 GEMM + f32 residual (EPI 18)"]["mfma_busy_frac"]]
+
+            def busy(prefix, grid):
+                return next(v["mfma_busy_frac"] for k_, v in kk_.items() if k_.startswith(prefix) and k_.endswith(f"grid {grid}"))
+            nt_m = (B * dims.n_audio_ctx + 255) // 256
+            g_qkv, g_d, g_f = nt_m * (3 * dims.d_model // 256) * 512, nt_m * (dims.d_model // 256) * 512, nt_m * (dims.ffn_dim // 256) * 512
+            fr = [busy("enc GEMM bias -> bf16", g_qkv), busy("enc GEMM bias -> bf16", g_d), busy("enc GEMM bias + GELU", g_f),
+                  busy("enc GEMM bias -> bf16", g_d)]
             pmc_busy = round(sum(x["flops"] for x in gs) / sum(x["flops"] / f_ for x, f_ in zip(gs, fr)), 4)
         except Exception:
             pass
@@ -403,7 +408,8 @@ def main():
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
-                     "frac": round(enc_tf / 2500.0, 4), "pmc_mfma_busy_frac": pmc_busy},
+                     "frac": round(enc_tf / 2500.0, 4), "pmc_mfma_busy_frac": pmc_busy,
+                     "pmc_source": "profiles/r2_pmc.json (static)"},
         }
         if check is not None:
             out["output_check"] = check

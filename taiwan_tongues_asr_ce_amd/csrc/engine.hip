@@ -46,10 +46,7 @@ struct ttasr_ctx {
   ttasr_config cfg{};
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t cur = nullptr;      // stream the schedule helpers enqueue on (stream, or stream2 for the second half-batch)
-  hipStream_t stream2 = nullptr;  // second decode chain (dual half-batch mode)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int dual_min_rows = 32;         // B >= this: split the decode step into two concurrent half-batch chains
+  hipStream_t cur = nullptr;      // stream the schedule helpers enqueue on
   std::string err;
   bool bf16 = false;
   bool finalized = false;
@@ -93,7 +90,7 @@ struct ttasr_ctx {
 #else
   static constexpr int skip_mask = 0;  // release builds cannot drop work from the decode step
 #endif
-  float* slab = nullptr;      // [2 chains][16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
+  float* slab = nullptr;      // [16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
   int ks_want[4] = {0, 0, 0, 0};  // TTASR_KS=d,q,qkv,fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
   int gemm_force = 0;         // TTASR_GEMM=v1|v2|v3 (A/B testing of the encoder GEMM kernels)
   bool no_flash = false;      // TTASR_NO_FLASH
@@ -330,7 +327,7 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(alloc_mat(c, &c->datt, B * d));
   TRY(alloc_mat(c, &c->dmid, B * c->ffn));
   TRY(dalloc(c, &c->logits, (size_t)B * c->ldv * 4));
-  TRY(dalloc(c, &c->slab, (size_t)2 * 16 * B * 3 * d * 4));  // one region per half-batch chain
+  TRY(dalloc(c, &c->slab, (size_t)16 * B * 3 * d * 4));
   c->max_new_alloc = c->cfg.n_text_ctx;
   c->max_prompt_alloc = c->cfg.n_text_ctx;
   TRY(dalloc(c, &c->st.cur_tok, B * 4)); TRY(dalloc(c, &c->st.step, 16)); TRY(dalloc(c, &c->st.n_sampled, B * 4));
@@ -488,8 +485,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   void *dh = tp(c->dh, d), *dqkv = tp(c->dqkv, 3 * d), *dq = tp(c->dq, d), *datt = tp(c->datt, d), *dmid = tp(c->dmid, ffn);
   float* logits = c->logits + (size_t)row0 * c->ldv;
   const bool skinny = sizeof(T) == 2 && !c->force_basic;
-  // the two half-batch chains (TTASR_DUAL) run concurrently on GEMMs of different widths: each has its own slab region
-  float* slab_base = c->slab + (row0 ? (size_t)16 * c->maxB * 3 * d : 0);
+  float* slab_base = c->slab;
   // K slices per GEMM kind (0 out-proj, 1 q, 2 qkv, 3 fc2); attention consumers sum at most 4 slabs
   auto slices = [&](int kind, int N, int K) {
     if (!skinny) return 1;
@@ -631,27 +627,13 @@ int prefill_positions(const ttasr_ctx* c, int min_plen, const ttasr_gen_opts* o)
   return p >= 2 ? p : 0;
 }
 
-// A decode step is a chain of ~350 launches of 4-8 us each, every one paying a launch boundary and a memory
-// round trip while most of the chip idles; only cross-attention is bandwidth-bound.  For B >= 32 the batch is
-// therefore split into two half-batches whose chains run CONCURRENTLY (two streams forked and joined inside the
-// captured graph): one chain's latency-bound kernels overlap the other's cross-attention stream.  Weights are
-// read twice per step (the second read mostly hits the Infinity Cache), which costs less than the idle time won.
+// One decode step = one dependent chain of ~355 launches on the context's stream, captured as a hipGraph.  Splitting the
+// batch into two half-batch chains on two streams inside the graph (round 1's TTASR_DUAL experiment: +4 % then) doubles the
+// launch count and, with the round-2 kernels, measures 3 % SLOWER (3.15 vs 3.05 ms per step): removed.
 template <typename T>
 void run_decode_step(ttasr_ctx* c, int B, int mode) {
-  const bool dual = c->stream2 && c->kv_div == 1 && B >= c->dual_min_rows && B % 2 == 0;
   c->cur = c->stream;
-  if (!dual) {
-    run_decode_rows<T>(c, 0, B, mode, B);
-  } else {
-    hipEventRecord(c->ev_fork, c->stream);
-    hipStreamWaitEvent(c->stream2, c->ev_fork, 0);
-    run_decode_rows<T>(c, 0, B / 2, mode, B);
-    c->cur = c->stream2;
-    run_decode_rows<T>(c, B / 2, B / 2, mode, B);
-    c->cur = c->stream;
-    hipEventRecord(c->ev_join, c->stream2);
-    hipStreamWaitEvent(c->stream, c->ev_join, 0);
-  }
+  run_decode_rows<T>(c, 0, B, mode, B);
   // modes 0 and 2 end with select_kernel, whose last workgroup advances the position; mode 1 has no select
   if (mode == 1 || (c->skip_mask & 16)) launch_advance(c->st.step, c->stream);
 }
@@ -817,15 +799,6 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
   p->cur = p->stream;
-  // opt-in (TTASR_DUAL=1): +4-5 % decode throughput at B = 32, but the cross-attention launches then run as two
-  // concurrent 16-row kernels, which muddies the per-launch roofline accounting; default is one chain.
-  if (getenv("TTASR_DUAL") != nullptr) {
-    if (hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess)
-      return die(fail(p, TTASR_E_HIP, "second decode stream creation failed"));
-  }
-  if (getenv("TTASR_DUAL_MIN")) p->dual_min_rows = atoi(getenv("TTASR_DUAL_MIN"));
   int rc = build_weights(p);
   if (rc) return die(rc);
   rc = build_workspaces(p);
@@ -843,9 +816,6 @@ void ttasr_destroy(ttasr_ctx* c) {
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
-  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }

@@ -21,11 +21,10 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "auto": {},                                            # default plan: K slices chosen automatically (d 4, q 4, qkv 2, fc2 8)
+    "d5": {"TTASR_KS": "5,5,2,8"},
+    "f16": {"TTASR_KS": "4,4,2,16"},
+    "f10": {"TTASR_KS": "4,4,2,10"},
     "qkv4": {"TTASR_KS": "4,4,4,8"},
-    "qkv1_q1": {"TTASR_KS": "4,1,1,8"},                    # only the residual GEMMs split (round-1 shape, slabs instead of atomics)
-    "d5_f16": {"TTASR_KS": "5,4,4,16"},
-    "d2_f4": {"TTASR_KS": "2,2,2,4"},
-    "dual": {"TTASR_DUAL": "1"},
     "w_plain": {"TTASR_W_NT": "0"},
     "xattn_plain": {"TTASR_XATTN": "0"},
 }
