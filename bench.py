@@ -154,26 +154,34 @@ def _self_launch(n: int) -> int:
     return max(abs(rc) for rc in rcs)
 
 
-def _host_greedy_prefix(eng, B, prompt, n_check, suppress, begin_suppress, eot):
-    """Recompute the first n_check greedy tokens of every row through the STEP API (ttasr_decode_step: raw logits to the
-    host, rules + first-maximum argmax applied here in numpy) on the cross-KV the last timed step left resident."""
+def _host_greedy_prefix(eng, B, prompt, tokens, n_check, suppress, begin_suppress, eot):
+    """Recompute the first n_check greedy choices of every row through the STEP API (ttasr_decode_step: raw logits to the
+    host, rules + first-maximum argmax applied here in numpy) on the cross-KV the last timed step left resident,
+    teacher-forced on the tokens the timed step produced.  The step API feeds the prompt token by token while generate()
+    prefills it in one batched pass (other GEMM tiles: the last bits of the cached keys differ), so a disagreement is only
+    accepted where the recomputed top-2 margin is within bf16 rounding distance of a tie.
+    -> (positions compared, positions that agree, largest margin at a disagreement)."""
     eng.decode_reset(B)
     logits = None
     for t in prompt:
         logits = eng.decode_step([t] * B)
     sup = np.asarray(sorted(set(suppress) | {eot}), dtype=np.int64)     # benchmark mode: EOT suppressed
     bsup = np.asarray(begin_suppress, dtype=np.int64)
-    out = np.zeros((B, n_check), dtype=np.int32)
+    agree, worst = 0, 0.0
     for i in range(n_check):
         lg = logits.copy()
         lg[:, sup] = -np.inf
         if i == 0:
             lg[:, bsup] = -np.inf
-        nxt = lg.argmax(axis=1).astype(np.int32)
-        out[:, i] = nxt
+        mine = lg.argmax(axis=1)
+        for b in range(B):
+            if mine[b] == tokens[b, i]:
+                agree += 1
+            else:
+                worst = max(worst, float(lg[b, mine[b]] - lg[b, tokens[b, i]]))
         if i + 1 < n_check:
-            logits = eng.decode_step(nxt.tolist())
-    return out
+            logits = eng.decode_step(tokens[:, i].tolist())
+    return B * n_check, agree, worst
 
 
 def main():
@@ -314,10 +322,10 @@ def main():
         host_ms = float(np.median(hs)) * 1e3
         del pcm_host
 
-    # What ties the timed work to correct output (rank 0): (i) the first tokens of EVERY row of the last timed step are
-    # recomputed through a different route - the step API hands raw logits to the host, the rules and the first-maximum
-    # argmax run in numpy - on the cross-KV that step left resident, and must be identical (the engine is bit-
-    # reproducible: no float atomics); (ii) a CRC-32 of all B x new_tokens token ids against the value recorded for this
+    # What ties the timed work to correct output (rank 0): (i) a replay of the step must be bit-identical (no float atomics);
+    # (ii) the first choices of EVERY row of the last timed step are recomputed through a different route - the step API
+    # hands raw logits to the host, the rules and the first-maximum argmax run in numpy, teacher-forced on the step's own
+    # tokens - and must agree except within rounding distance of a tie; (iii) a CRC-32 of all B x new_tokens token ids against the value recorded for this
     # configuration in profiles/bench_tokens_crc.json (a tripwire for skipped work / changed arithmetic; rewritten with
     # --write-crc when a kernel change legitimately alters the last bits).  Logit-level parity of the same kernels
     # against the oracle is the job of tests/ (test_gpu_full_size.py at this geometry).
@@ -328,8 +336,8 @@ def main():
         mine = np.asarray(toks[:B], dtype=np.int32)
         again = one_pass(eng)            # also restores this rank's resident state after the validation probe
         replay_equal = all(list(mine[b, :len(t)]) == list(t) for b, t in enumerate(again))
-        redo = _host_greedy_prefix(eng, B, prompt, n_chk, [opts.suppress[i] for i in range(opts.n_suppress)],
-                                   [opts.begin_suppress[i] for i in range(opts.n_begin_suppress)], st.eot)
+        n_cmp, n_agree, worst = _host_greedy_prefix(eng, B, prompt, mine, n_chk, [opts.suppress[i] for i in range(opts.n_suppress)],
+                                                    [opts.begin_suppress[i] for i in range(opts.n_begin_suppress)], st.eot)
         crc = zlib.crc32(np.ascontiguousarray(mine).tobytes()) & 0xFFFFFFFF
         key = f"{args.model}/b{B}/n{args.new_tokens}/{args.compute}"
         crc_path = os.path.join(ROOT, "profiles", "bench_tokens_crc.json")
@@ -342,11 +350,12 @@ def main():
             known[key] = crc
             with open(crc_path, "w") as f:
                 json.dump(known, f, indent=1, sort_keys=True)
-        check = {"replay_bit_identical": bool(replay_equal), "prefix_tokens_recomputed_via_step_api": n_chk, "prefix_equal": bool(np.array_equal(redo, mine[:, :n_chk])),
+        tol = 0.05 if args.compute == "bf16" else 1e-3
+        check = {"replay_bit_identical": bool(replay_equal), "prefix_choices_recomputed_via_step_api": n_cmp,
+                 "prefix_choices_equal": n_agree, "largest_margin_at_a_disagreement": round(worst, 5), "margin_tolerance": tol,
                  "tokens_crc32": crc, "expected_crc32": known.get(key), "crc_match": (known.get(key) == crc) if key in known else None}
-        if not check["prefix_equal"] or not replay_equal:
-            raise SystemExit(f"output check failed: greedy tokens of the timed step differ from the step-API recomputation\n"
-                             f"{mine[:2, :n_chk].tolist()} vs {redo[:2].tolist()}")
+        if worst > tol or n_agree < 0.9 * n_cmp or not replay_equal:
+            raise SystemExit(f"output check failed: {check}")
         # the recomputation moved the decode state: rebuild the step's state for the kernel measurements below
         one_pass(eng)
 

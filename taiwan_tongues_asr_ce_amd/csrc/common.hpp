@@ -176,6 +176,7 @@ template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel /*[H] dev*/,
                              float* probs /*[n_sel][rows][Tk]*/, hipStream_t s);
 void launch_token_logprob(const float* logits, int ldv, int V, const int32_t* target, float* out, int rows, hipStream_t s);
+void launch_token_prob(const float* logits, int ldv, int V, int tok, float* out /*[rows]*/, int rows, hipStream_t s);
 template <typename T>
 void launch_embed_prefill(const int32_t* prompt, int max_prompt, int rows_per_prompt, int n_seq, int npos, const T* emb, const T* pos,
                           float* x, int d, hipStream_t s);

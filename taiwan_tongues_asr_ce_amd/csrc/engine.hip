@@ -94,6 +94,7 @@ struct ttasr_ctx {
   int ks_want[4] = {0, 0, 0, 0};  // TTASR_KS=d,q,qkv,fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
   int gemm_force = 0;         // TTASR_GEMM=v1|v2|v3 (A/B testing of the encoder GEMM kernels)
   bool no_flash = false;      // TTASR_NO_FLASH
+  int prefill_ns_min = 16;    // TTASR_PREFILL_NS_MIN: shortest prompt whose sot position is taken from the prefill pass
   bool enc_res_epilogue = false;  // TTASR_ENC_RES_EPI: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
@@ -616,15 +617,33 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
   }
 }
 
-// How many leading prompt positions can be prefilled: every row must still have a forced token after them, the
-// no-speech probability needs real logits at the <|startoftranscript|> position, and the rows must fit the
-// borrowed encoder workspaces.  Below 2 positions the pass does not pay.
-int prefill_positions(const ttasr_ctx* c, int min_plen, const ttasr_gen_opts* o) {
+// How many leading prompt positions can be prefilled: every row must still have a forced token after them and the rows
+// must fit the borrowed encoder workspaces.  Below 2 positions the pass does not pay.  `ns_from_prefill` = the caller can
+// take the no-speech probability from the prefilled <|startoftranscript|> position (prefill_no_speech); otherwise that
+// position needs a real decode step and bounds the prefill.
+int prefill_positions(const ttasr_ctx* c, int min_plen, const ttasr_gen_opts* o, bool ns_from_prefill = false) {
   if (c->no_prefill) return 0;
   int p = min_plen - 1;
-  if (o->no_speech >= 0) p = std::min(p, o->sot_index);
+  if (o->no_speech >= 0 && !ns_from_prefill) p = std::min(p, o->sot_index);
   p = std::min(p, c->cfg.n_audio_ctx);
   return p >= 2 ? p : 0;
+}
+
+// No-speech probability from a prefill pass: the residual rows of position `sot` of every sequence (left in c->x by
+// run_prefill, rows [sequence][position]) -> final LayerNorm -> vocabulary projection -> softmax(raw logits)[no_speech].
+template <typename T>
+int prefill_no_speech(ttasr_ctx* c, int n_seq, int npos, int sot, int no_speech_tok) {
+  hipStream_t s = c->stream;
+  const int d = c->d;
+  c->cur = s;
+  HIPCHK(c, hipMemcpy2DAsync(c->dx, (size_t)d * 4, c->x + (size_t)sot * d, (size_t)npos * d * 4, (size_t)d * 4, n_seq,
+                             hipMemcpyDeviceToDevice, s));
+  launch_layernorm_rows<T>(c->dx, c->dlnf_g, c->dlnf_b, (T*)c->dh, n_seq, d, LnPre{}, s);
+  GemmArgs g = lin_args<T>(c->dh, c->emb, n_seq, c->V, d);
+  g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
+  dec_gemm<T>(c, g, c->emb_sh);
+  launch_token_prob(c->logits, c->ldv, c->V, no_speech_tok, c->st.no_speech, n_seq, s);
+  return 0;
 }
 
 // One decode step = one dependent chain of ~355 launches on the context's stream, captured as a hipGraph.  Splitting the
@@ -788,6 +807,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
 #endif
   if (const char* v = getenv("TTASR_KS")) sscanf(v, "%d,%d,%d,%d", &c->ks_want[0], &c->ks_want[1], &c->ks_want[2], &c->ks_want[3]);
   c->no_flash = getenv("TTASR_NO_FLASH") != nullptr;
+  if (const char* v = getenv("TTASR_PREFILL_NS_MIN")) c->prefill_ns_min = atoi(v);
   c->enc_res_epilogue = getenv("TTASR_ENC_RES_EPI") != nullptr;
   if (const char* v = getenv("TTASR_GEMM")) c->gemm_force = (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0;
   if (const char* v = getenv("TTASR_XATTN")) g_xattn_variant = atoi(v);
@@ -1113,9 +1133,16 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   // from position n_text_ctx - 2 is the last one, position n_text_ctx - 1 is never fed)
   const int last_step = std::min(c->cfg.n_text_ctx - 1, max_plen - 1 + o->max_new_tokens);
   hipEventRecord(c->ev[5], s);
-  const int pre = prefill_positions(c, min_plen, o);
+  // A prefill pass runs the encoder-side GEMM kernels on rows x positions; for a handful of positions that costs more
+  // than the decode steps it replaces (measured at large-v3, 3 positions x 32 rows: +5 ms), so the
+  // <|startoftranscript|> position is only folded into the prefill when the prompt is long (previous-text prompts)
+  const int pre = prefill_positions(c, min_plen, o, /*ns_from_prefill=*/min_plen - 1 >= c->prefill_ns_min);
   if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
     if (c->bf16) run_prefill<bf16_t>(c, R, pre, rows_per_clip, max_prompt); else run_prefill<float>(c, R, pre, rows_per_clip, max_prompt);
+    if (o->no_speech >= 0 && o->sot_index < pre) {  // the <|startoftranscript|> position was prefilled: its logits come from here
+      if (c->bf16) TRY(prefill_no_speech<bf16_t>(c, R, pre, o->sot_index, o->no_speech));
+      else TRY(prefill_no_speech<float>(c, R, pre, o->sot_index, o->no_speech));
+    }
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev + pre, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));

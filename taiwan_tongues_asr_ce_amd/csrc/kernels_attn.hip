@@ -197,18 +197,19 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
   if (MODE != 1) load_kv(0);
   float q[VEC], kn[VEC], vn[VEC];
   if constexpr (SLAB) {  // qkv GEMM was K-split: complete q, k, v from its partial tiles
-    // waves 0 / 1 / 2 sum q / k / v (their first LPR lanes, one 16-byte chunk each) and share them through LDS:
-    // 24 lanes issue the slab loads instead of all 256
-    __shared__ float qkv_s[3][64];
-    if (wave < 3 && rin == 0) {
-      float t[VEC];
-      load_row_slabs<T>(sq, (int64_t)b * 3 * d + wave * d + h * 64 + sub * VEC, t);
+    // q is needed by every lane: the first LPR lanes of each wave sum one 16-byte chunk each and the wave shares them by
+    // shuffles (lane `sub` holds chunk `sub`); k and v of this step are only needed by the lanes that append them and score
+    // the new key (wave 0's first LPR lanes).  No LDS, no barrier in front of the cached-key loop.
+    float t[VEC];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) qkv_s[wave][sub * VEC + j] = t[j];
+    for (int j = 0; j < VEC; ++j) { t[j] = 0.f; kn[j] = 0.f; vn[j] = 0.f; }
+    const int64_t off = (int64_t)b * 3 * d + h * 64 + sub * VEC;
+    if (rin == 0) {
+      load_row_slabs<T>(sq, off, t);
+      if (wave == 0) { load_row_slabs<T>(sq, off + d, kn); load_row_slabs<T>(sq, off + 2 * d, vn); }
     }
-    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { q[j] = qkv_s[0][sub * VEC + j]; kn[j] = qkv_s[1][sub * VEC + j]; vn[j] = qkv_s[2][sub * VEC + j]; }
+    for (int j = 0; j < VEC; ++j) q[j] = __shfl(t[j], sub);
   } else {
     RowVec<T>::load(qp + sub * VEC, q);
     RowVec<T>::load(qp + d + sub * VEC, kn);

@@ -265,6 +265,31 @@ __global__ __launch_bounds__(256) void token_logprob_kernel(const float* __restr
   __syncthreads();
   if (tid == 0) out[b] = row[target[b]] - m - __logf((red[0] + red[1]) + (red[2] + red[3]));
 }
+// softmax(row)[tok] of raw logits, one workgroup per row: the no-speech probability when the <|startoftranscript|> position
+// was computed by the batched prompt prefill instead of a decode step (HF logits_process.py:2050-2113: probability of
+// <|nospeech|> under the unprocessed distribution at the sot position)
+__global__ __launch_bounds__(256) void token_prob_kernel(const float* __restrict__ logits, int ldv, int V, int tok,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (int64_t)b * ldv;
+  float m = -INFINITY;
+  for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = tid; i < V; i += 256) sum += __expf(row[i] - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  if (tid == 0) out[b] = __expf(row[tok] - m) / ((red[0] + red[1]) + (red[2] + red[3]));
+}
+void launch_token_prob(const float* logits, int ldv, int V, int tok, float* out, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(token_prob_kernel, dim3(rows), dim3(256), 0, s, logits, ldv, V, tok, out);
+}
 void launch_token_logprob(const float* logits, int ldv, int V, const int32_t* target, float* out, int rows, hipStream_t s) {
   hipLaunchKernelGGL(token_logprob_kernel, dim3(rows), dim3(256), 0, s, logits, ldv, V, target, out);
 }

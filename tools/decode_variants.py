@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "auto": {},                                            # default plan: K slices chosen automatically (d 4, q 4, qkv 2, fc2 8)
+    "prefill_sot": {"TTASR_PREFILL_NS_MIN": "2"},
     "d5": {"TTASR_KS": "5,5,2,8"},
     "f16": {"TTASR_KS": "4,4,2,16"},
     "f10": {"TTASR_KS": "4,4,2,10"},
