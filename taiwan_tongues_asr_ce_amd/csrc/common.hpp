@@ -11,11 +11,13 @@ using s16x8 = __attribute__((ext_vector_type(8))) short;
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH "Correctness boundaries")
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH "Correctness boundaries"): gfx950's v_cvt_pk_bf16_f32, one
+// instruction per PAIR of values instead of the ~8-instruction integer sequence with a NaN branch
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+  typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+  typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){lo, hi}, bf16x2_hw));
 }
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }

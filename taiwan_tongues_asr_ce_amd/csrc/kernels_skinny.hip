@@ -41,10 +41,10 @@ __global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __res
     if (r >= rows) continue;
     const float* s = src + (int64_t)r * K + ks * 16 + 8 * (lane >> 5);
     uint4 o;
-    o.x = (uint32_t)f2bf(s[0]) | ((uint32_t)f2bf(s[1]) << 16);
-    o.y = (uint32_t)f2bf(s[2]) | ((uint32_t)f2bf(s[3]) << 16);
-    o.z = (uint32_t)f2bf(s[4]) | ((uint32_t)f2bf(s[5]) << 16);
-    o.w = (uint32_t)f2bf(s[6]) | ((uint32_t)f2bf(s[7]) << 16);
+    o.x = f2bf_pk(s[0], s[1]);
+    o.y = f2bf_pk(s[2], s[3]);
+    o.z = f2bf_pk(s[4], s[5]);
+    o.w = f2bf_pk(s[6], s[7]);
     ((uint4*)dst)[((int64_t)(nb + row_offset / 32) * ks_per + ks) * 64 + lane] = o;
   }
 }
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
       if (e.out_f32) *(float4*)(e.out_f32 + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
       if (e.out_t) {
         uint2 pk;
-        pk.x = (uint32_t)f2bf(vv[0]) | ((uint32_t)f2bf(vv[1]) << 16);
-        pk.y = (uint32_t)f2bf(vv[2]) | ((uint32_t)f2bf(vv[3]) << 16);
+        pk.x = f2bf_pk(vv[0], vv[1]);
+        pk.y = f2bf_pk(vv[2], vv[3]);
         *(uint2*)((bf16_t*)e.out_t + idx0) = pk;
       }
       continue;

@@ -8,7 +8,7 @@ import torch
 
 from oracle import whisper_ref as R
 from taiwan_tongues_asr_ce_amd import synth
-from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, WhisperDims
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, PRESETS, WhisperDims
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
@@ -76,3 +76,31 @@ def test_width_parity_f32_and_bf16(dims):
             assert float(s.max() - s[c]) < 0.15
             nxt.append(c)
         logits = R.decoder_forward(torch.tensor(nxt)[:, None], cache, xkv, Wb, rd)[:, 0]
+
+
+@pytest.mark.gpu
+def test_flash_attention_matches_the_plain_attention_kernel_at_ragged_windows(monkeypatch):
+    """The MFMA flash kernel (kernels_flash.hip: 64-key tiles, last tile masked, softmax denominator summed by an all-ones
+    MFMA over the bf16-rounded weights) against the one-query-per-wave kernel (TTASR_NO_FLASH) on the same bf16 q, k, v:
+    the 2-layer encoder output agrees to bf16 rounding at windows that end inside a key tile (1500 = 23 x 64 + 28; 150),
+    exactly on one (64, 128), on a single partial tile (20) and on an even tile count (200)."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    dims = PRESETS["large-v3-w2"]
+    clips = [synth.tonal_clip(0), synth.noise_clip(1), synth.tonal_clip(2)]
+    windows = (0, 20, 64, 128, 150, 200)
+    outs = {}
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("TTASR_NO_FLASH", "1")
+        e = Engine(dims, COMPUTE_BF16, 3)
+        e.load_weights(synth.iter_weights(dims))
+        for n_ctx in windows:
+            e.set_audio_ctx(n_ctx)
+            e.log_mel(clips, want_output=False)
+            outs[plain, n_ctx] = e.encode(3, want_output=True).copy()
+        e.close()
+    for n_ctx in windows:
+        a, b = outs[False, n_ctx], outs[True, n_ctx]
+        assert np.isfinite(a).all()
+        err = np.abs(a - b)
+        assert err.max() < 0.05 and err.mean() < 0.004, (n_ctx, float(err.max()), float(err.mean()))
