@@ -1619,7 +1619,8 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
   auto once = [&](void) -> int {
     if (k == "xattn") {
       static int layer_rr = 0;  // walk the layers: one layer's K/V (246 MB at B=32) would sit in the Infinity Cache
-      const char* Kx = (const char*)c->xkv + (size_t)(layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
+      static const bool same_layer = getenv("TTASR_BENCH_XATTN_SAME_LAYER") != nullptr;  // (that case, for comparison)
+      const char* Kx = (const char*)c->xkv + (size_t)(same_layer ? 0 : layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
       if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
                                                     (bf16_t*)c->datt, B, c->H, c->T, 1, s);
       else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,

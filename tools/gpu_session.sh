@@ -1,21 +1,20 @@
 set -x
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r2r; mkdir -p $O
-timeout 300 python - > $O/flash_dbg.txt 2>&1 <<'PY'
-import ctypes, json
-from taiwan_tongues_asr_ce_amd import synth
-from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
-from taiwan_tongues_asr_ce_amd.engine import Engine
-dims = PRESETS["large-v3"]
-e = Engine(dims, COMPUTE_BF16, 32); e.load_weights(synth.iter_weights(dims))
-e.log_mel([synth.noise_clip(b) for b in range(32)], want_output=False); e.encode(32)
-var = ctypes.c_int.in_dll(e.lib, "g_flash_dbg")
-names = {0: "real", 1: "no global loads / LDS stores in the loop", 2: "no exp (add only)", 3: "no PV MFMAs (sum MFMA only)", 4: "real, 2 WG/CU", 5: "real, 1 WG/CU"}
-for rep in range(2):
-    for v in range(6):
-        var.value = v
-        k = e.bench_kernel("enc_attn", 32, iters=20)
-        print(json.dumps({"dbg": v, "what": names[v], "us": round(k["ms"]*1e3, 1)}), flush=True)
-e.close()
-PY
-cat $O/flash_dbg.txt
+O=$GRAFT_REPO_ROOT/gpurun_out/r2t; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"
+tail -4 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 600 python bench.py --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+cat $O/bench.json | head -c 2500; tail -3 $O/bench.err
+cp profiles/bench_tokens_crc.json $O/
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
+f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -5 $O/kernel_stats.csv | cut -c1-250; rm -rf $O/prof
+cat $O/prof_bench.json | head -c 600
+for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
+  tag=$(echo $p | cut -d' ' -f1)
+  timeout 900 rocprofv3 --pmc $p --output-format csv -d $O/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
+done
+python tools/microbench/pmc_report.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES r2 $O > $O/pmc_report.txt 2>&1; tail -5 $O/pmc_report.txt
+cat $O/xattn_pmc.json
+find $O -name "*counter_collection.csv" -delete; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
