@@ -28,16 +28,51 @@ template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Cross-lane reductions without the LDS crossbar: `__shfl_xor` is ds_bpermute_b32 (an LDS round trip, ~100 cycles, and the
+// butterfly is a chain of six of them); within a row of 16 lanes the DPP modifiers move data inside the VALU (quad_perm,
+// row_half_mirror, row_mirror, row_ror), and gfx950's v_permlane16_swap / v_permlane32_swap exchange rows and wave halves.
+// Every lane ends with the result, as with the xor butterfly (the association order differs: not the same bits).
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {  // every lane has a source lane for the controls used here
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1 /*quad_perm [1,0,3,2]*/, DPP_XOR2 = 0x4E /*quad_perm [2,3,0,1]*/, DPP_HALF_MIRROR = 0x141 /*i <-> 7-i*/,
+              DPP_MIRROR = 0x140 /*i <-> 15-i*/, DPP_ROR8 = 0x128 /*i <- (i+8)%16: lane ^ 8*/;
+struct OpSum { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+// combine with the lanes 16 / 32 away (lane ^ 16, lane ^ 32): swap(v, v) leaves {v.r0, v.r0, v.r2, v.r2} and {v.r1, v.r1, v.r3, v.r3}
+// (rows of 16), resp. {v.lo, v.lo} and {v.hi, v.hi} (halves) - op() of the two is op(v, v[lane ^ 16 or 32]) in every lane
+// (the results are copied to scalars first: __builtin_bit_cast applied to r[1] directly reads element 0 with this compiler)
+template <typename Op> __device__ __forceinline__ float xor16_reduce(float v, Op op) {
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+}
+template <typename Op> __device__ __forceinline__ float xor32_reduce(float v, Op op) {
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  return op(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+}
+// reduce over aligned groups of N consecutive lanes (N = 2 .. 64)
+template <int N, typename Op> __device__ __forceinline__ float group_reduce(float v, Op op) {
+  if constexpr (N >= 2) v = op(v, dpp_f<DPP_XOR1>(v));
+  if constexpr (N >= 4) v = op(v, dpp_f<DPP_XOR2>(v));
+  if constexpr (N >= 8) v = op(v, dpp_f<DPP_HALF_MIRROR>(v));
+  if constexpr (N >= 16) v = op(v, dpp_f<DPP_MIRROR>(v));
+  if constexpr (N >= 32) v = xor16_reduce(v, op);
+  if constexpr (N >= 64) v = xor32_reduce(v, op);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+// reduce over the lanes that share (lane % N): the values N, 2N, ... lanes apart (N = 8, 16, 32)
+template <int N, typename Op> __device__ __forceinline__ float stride_reduce(float v, Op op) {
+  if constexpr (N <= 8) v = op(v, dpp_f<DPP_ROR8>(v));
+  if constexpr (N <= 16) v = xor16_reduce(v, op);
+  v = xor32_reduce(v, op);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_reduce<64>(v, OpSum{}); }
+__device__ __forceinline__ float wave_max(float v) { return group_reduce<64>(v, OpMax{}); }
 
 // Kernel arguments live in the kernarg segment and reach SGPRs through s_load; the compiler treats those loads as free to
 // re-materialise and sinks them next to their first use, which in these kernels produced two or three SERIALISED

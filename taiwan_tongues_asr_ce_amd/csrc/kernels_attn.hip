@@ -235,8 +235,7 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kv[u][j], s);
-#pragma unroll
-      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+      s = group_reduce<LPR>(s, OpSum{});
       if (t < pos) {
         const float mn = fmaxf(m_run, s);
         const float sc = __expf(m_run - mn), p = __expf(s - mn);
@@ -251,8 +250,7 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s = fmaf(q[j], kn[j], s);
-#pragma unroll
-    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+    s = group_reduce<LPR>(s, OpSum{});
     const float mn = fmaxf(m_run, s);
     const float sc = __expf(m_run - mn), p = __expf(s - mn);
     l_run = l_run * sc + p;
@@ -271,8 +269,7 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     acc[j] *= wgt;
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+    acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
   }
   if (lane == 0) red[wave][1] = lw;
   if (rin == 0) {
@@ -403,8 +400,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
 #pragma unroll
         for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kv[u][j], s);
       }
-#pragma unroll
-      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+      s = group_reduce<LPR>(s, OpSum{});
       if (t < Tk) {
         if (sub == 0) sc[t] = s;
         mloc = fmaxf(mloc, s);
@@ -461,8 +457,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+    acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
   }
   if (rin == 0) {
 #pragma unroll
@@ -519,8 +514,7 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kv[u][j], s);
-#pragma unroll
-      for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+      s = group_reduce<LPR>(s, OpSum{});
       if (t < n) {
         if (sub == 0) sc[t] = s;
         mloc = fmaxf(mloc, s);
@@ -563,8 +557,7 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
   }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) acc[j] += __shfl_xor(acc[j], o);
+    acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
   }
   if (rin == 0) {
 #pragma unroll

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, s[0][j]);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, s[1][j]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    tmax = xor32_reduce(tmax, OpMax{});  // v_permlane32_swap: no LDS round trip in the tile loop
     const float m_new = fmaxf(m_run, tmax);
     const float mb = -m_new * LOG2E;
     float psum = 0.f;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   tile(n_tiles - 1, std::true_type{});
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = xor32_reduce(l_run, OpSum{});
   const float inv = 1.0f / l_tot;
   char* ob = smem + wave * (32 * 144);  // [32 q][64 d] bf16, row stride 144 B (128 + 16 pad)
 #pragma unroll

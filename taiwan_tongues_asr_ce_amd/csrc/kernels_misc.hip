@@ -271,6 +271,7 @@ template <typename T, int MAXS, bool EMBED>
 __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __restrict__ x_, const float* __restrict__ gamma_,
                                                              const float* __restrict__ beta_, T* __restrict__ out_, int d_,
                                                              LnPre pre) {
+  constexpr int NWAVE = 5;  // always launched with 320 threads (d <= 1280): the cross-wave sums are five fixed reads, no loop
   __shared__ float red[2][8];
   // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin)
   const float* x = sgpr_pin_ptr(x_); const float* gamma = sgpr_pin_ptr(gamma_); const float* beta = sgpr_pin_ptr(beta_);
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
   pre.bias = sgpr_pin_ptr(pre.bias); pre.slab = sgpr_pin_ptr(pre.slab); pre.n_slab = sgpr_pin(pre.n_slab);
   pre.slab_stride = sgpr_pin(pre.slab_stride); pre.x_out = sgpr_pin_ptr(pre.x_out);
   if constexpr (EMBED) { pre.tok = sgpr_pin_ptr(pre.tok); pre.step = sgpr_pin_ptr(pre.step); pre.emb = sgpr_pin_ptr(pre.emb); pre.pos = sgpr_pin_ptr(pre.pos); }
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = d >> 2, i = min(tid, nv - 1);
   const bool live = tid < nv;
+  const float inv_d = __builtin_amdgcn_rcpf((float)d);  // computed while the loads fly (a division here is ten dependent instructions)
   float4 v;
   const float4 gm = ((const float4*)gamma)[i], bt = ((const float4*)beta)[i];
   if constexpr (EMBED) {
@@ -319,17 +321,14 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
   s1 = wave_sum(s1);
   if (lane == 0) red[0][wave] = s1;
   __syncthreads();
-  float tot = 0.f;
-  for (int w = 0; w < nwave; ++w) tot += red[0][w];
-  const float mean = tot / d;
+  static_assert(NWAVE == 5, "fixed-order sum of the five wave partials");
+  const float mean = (((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) + red[0][4]) * inv_d;
   const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
   float s2 = live ? (a * a + b * b) + (c * c + e * e) : 0.f;
   s2 = wave_sum(s2);
   if (lane == 0) red[1][wave] = s2;
   __syncthreads();
-  float tot2 = 0.f;
-  for (int w = 0; w < nwave; ++w) tot2 += red[1][w];
-  const float rstd = rsqrtf(tot2 / d + 1e-5f);
+  const float rstd = rsqrtf((((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) + red[1][4]) * inv_d + 1e-5f);
   if (!live) return;
   const float r0 = a * rstd * gm.x + bt.x, r1 = b * rstd * gm.y + bt.y, r2 = c * rstd * gm.z + bt.z, r3 = e * rstd * gm.w + bt.w;
   T* o = out + (int64_t)row * d;
@@ -347,8 +346,8 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
 template <typename T>
 void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const LnPre& pre,
                            hipStream_t s) {
-  const int threads = ((d / 4) + 63) / 64 * 64;  // d <= 1280 (ttasr_create) -> <= 320 threads
-  dim3 grid(rows), block(threads);
+  if (d > 1280 || (d & 3)) { fprintf(stderr, "ttasr: layernorm_rows needs d <= 1280, d %% 4 == 0 (got %d)\n", d); abort(); }
+  dim3 grid(rows), block(320);  // five waves whatever d is (ttasr_create: d <= 1280): threads past d / 4 contribute zeros
   if (pre.tok) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, true>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab == 0) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 2) hipLaunchKernelGGL((layernorm_rows_kernel<T, 2, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
