@@ -77,6 +77,8 @@ typedef struct ttasr_gen_opts {
 } ttasr_gen_opts;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */
+/* Geometry limits (TTASR_E_INVALID otherwise): d_model <= 1280, vocab <= 53248 (every Whisper checkpoint: <= 1280, <= 51866),
+ * n_mels % 8 == 0, ffn_dim % 64 == 0. */
 int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx);
 void ttasr_destroy(ttasr_ctx* ctx);
 /* Message of the last failing call on this context (ctx == NULL: last ttasr_create failure). */

@@ -782,6 +782,8 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (cfg->d_model <= 0 || cfg->n_heads <= 0 || cfg->d_model != cfg->n_heads * 64)
     return fail(nullptr, TTASR_E_INVALID, "head_dim must be 64 (d_model=%d, n_heads=%d)", cfg->d_model, cfg->n_heads);
   if (cfg->d_model > 1280) return fail(nullptr, TTASR_E_INVALID, "d_model %d > 1280 (LayerNorm keeps a row in registers)", cfg->d_model);
+  if (cfg->vocab > 13 * 4096)  // kernels_decode.hip LOGIT_NIT: Whisper vocabularies are 51 864 .. 51 866
+    return fail(nullptr, TTASR_E_INVALID, "vocab %d > 53248 (the token-selection kernels keep a logits row in registers)", cfg->vocab);
   if (cfg->n_mels % 8 || cfg->n_mels <= 0 || cfg->ffn_dim % 64 || cfg->n_audio_ctx < 1 || cfg->vocab < 2 ||
       cfg->n_text_ctx < 2 || cfg->n_text_ctx > 448 || cfg->enc_layers < 1 || cfg->dec_layers < 1 || cfg->max_batch < 1)
     return fail(nullptr, TTASR_E_INVALID, "unsupported geometry");

@@ -103,11 +103,12 @@ template <> struct RowVec<bf16_t> {
 // v = round_T(bias + slab[0] + ... + slab[n-1]) in slab order (bit-reproducible), i.e. exactly what the unsplit GEMM's
 // epilogue would have stored.  All loads are issued first (slab index clamped), n <= 4.
 template <typename T>
-__device__ __forceinline__ void load_row_slabs(const SlabIn& si, int64_t off, float (&v)[RowVec<T>::VEC]) {
+__device__ __forceinline__ void load_row_slabs(const SlabIn& si, int64_t off, int col /*= off % si.ld, known to the caller*/,
+                                               float (&v)[RowVec<T>::VEC]) {
   constexpr int VEC = RowVec<T>::VEC, NF4 = VEC / 4, MAXS = 4;
   float4 t[MAXS][NF4], bs[NF4];
 #pragma unroll
-  for (int c = 0; c < NF4; ++c) bs[c] = *(const float4*)(si.bias + (off % si.ld) + 4 * c);
+  for (int c = 0; c < NF4; ++c) bs[c] = *(const float4*)(si.bias + col + 4 * c);
 #pragma unroll
   for (int s = 0; s < MAXS; ++s) {
     const float* p = si.slab + (int64_t)min(s, si.n - 1) * si.stride + off;
@@ -205,8 +206,9 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
     for (int j = 0; j < VEC; ++j) { t[j] = 0.f; kn[j] = 0.f; vn[j] = 0.f; }
     const int64_t off = (int64_t)b * 3 * d + h * 64 + sub * VEC;
     if (rin == 0) {
-      load_row_slabs<T>(sq, off, t);
-      if (wave == 0) { load_row_slabs<T>(sq, off + d, kn); load_row_slabs<T>(sq, off + 2 * d, vn); }
+      const int col = h * 64 + sub * VEC;
+      load_row_slabs<T>(sq, off, col, t);
+      if (wave == 0) { load_row_slabs<T>(sq, off + d, col + d, kn); load_row_slabs<T>(sq, off + 2 * d, col + 2 * d, vn); }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) q[j] = __shfl(t[j], sub);
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + Tk;          // [NWV][64]
   float* red = part + NWV * 64;   // [2 * NWV]
-  const int bk = b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
+  const int bk = kv_div == 1 ? b : b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
   const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64;
   const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64;
   float mloc = -1e30f;
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   // tiles): the stream starts one round trip after launch instead of two
   load_k(0);
   float qv[VEC];
-  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);  // q GEMM was K-split
+  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);  // q GEMM was K-split
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
     if (it0 > 0) load_k(it0);
@@ -493,9 +495,9 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
   float* part = sc + chunk;
   float* red = part + 4 * 64;
   float qv[VEC];
-  if (sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, qv);
+  if (sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
-  const int bk = b / kv_div;
+  const int bk = kv_div == 1 ? b : b / kv_div;
   const int t0 = z * chunk, n = min(chunk, Tk - t0);  // this slice: frames t0 .. t0+n-1 (n >= 1 by construction)
   const T* Kp = K + (((int64_t)bk * H + h) * Tk + t0) * 64;
   const T* Vp = V + (((int64_t)bk * H + h) * Tk + t0) * 64;
@@ -616,27 +618,17 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
     hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
     return;
   }
-  // g_xattn_variant (TTASR_XATTN, A/B testing): bit 0 nontemporal K/V loads, bit 1 16 rows in flight per lane, bit 2 8 waves
-  const int var = g_xattn_variant;
-  const int nwv = (var & 4) ? 8 : 4;
-  size_t lds = sizeof(float) * (Tk + nwv * 64 + 2 * nwv);
-#define TTASR_XA(NWV_, UN_, NT_)                                                                                          \
-  do {                                                                                                                    \
-    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_, true>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
-                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                               \
-    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, NWV_, UN_, NT_, false>), dim3(H, B), dim3(NWV_ * 64), lds, s, q, K, V, out, H, \
-                            Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                                        \
+  // g_xattn_variant (TTASR_XATTN, A/B testing): 1 = nontemporal K/V loads (default), 0 = plain.  (16 rows in flight per lane and
+  // 8-wave workgroups were measured slower - DESIGN.md 4.11a - and are no longer instantiated.)
+  size_t lds = sizeof(float) * (Tk + 4 * 64 + 2 * 4);
+#define TTASR_XA(NT_)                                                                                                                  \
+  do {                                                                                                                                 \
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, true>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, \
+                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                                            \
+    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, false>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,  \
+                            kv_div, (const int*)nullptr, (float*)nullptr, sq);                                                         \
   } while (0)
-  switch (var & 7) {
-    case 1: TTASR_XA(4, 8, true); break;
-    case 2: TTASR_XA(4, 16, false); break;
-    case 3: TTASR_XA(4, 16, true); break;
-    case 4: TTASR_XA(8, 8, false); break;
-    case 5: TTASR_XA(8, 8, true); break;
-    case 6: TTASR_XA(8, 4, false); break;
-    case 7: TTASR_XA(8, 4, true); break;
-    default: TTASR_XA(4, 8, false); break;
-  }
+  if (g_xattn_variant & 1) TTASR_XA(true); else TTASR_XA(false);
 #undef TTASR_XA
 }
 // alignment pass: rows = token positions of one sequence; heads with sel[h] >= 0 dump their attention rows

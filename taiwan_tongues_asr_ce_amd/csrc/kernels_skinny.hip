@@ -65,7 +65,7 @@ int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (TTASR_W_N
 // before the bulk of the weight loads is even issued: one more serialised round trip.)
 template <int NW, int RB, int U, bool NT, bool ONE>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh_, const bf16_t* __restrict__ x_,
-                                                              int B_, int N_, int K_, int ksplit_, GemmEpi e,
+                                                              int B_, int N_, int K_, int ksplit_, int steps_, GemmEpi e,
                                                               float* __restrict__ slab_, int64_t slab_stride_) {
   // U = k-steps in flight per wave (register budget: U * (1 + RB) * 4); the launcher picks the smallest instantiated
   // U >= steps so that no load is issued twice
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   const bf16_t* Wsh = sgpr_pin_ptr(Wsh_);
   const bf16_t* x = sgpr_pin_ptr(x_);
   const int B = sgpr_pin(B_), N = sgpr_pin(N_), K = sgpr_pin(K_), ksplit = sgpr_pin(ksplit_);
+  const int steps = sgpr_pin(steps_);  // k-steps per wave = K / 16 / (NW * ksplit), divided on the host: an integer division here is
+                                       // ~40 dependent instructions in front of the first load
   float* slab = sgpr_pin_ptr(slab_);
   const int64_t slab_stride = sgpr_pin(slab_stride_);
   e.bias = sgpr_pin_ptr(e.bias); e.residual = sgpr_pin_ptr(e.residual); e.out_f32 = sgpr_pin_ptr(e.out_f32);
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.x, ks = blockIdx.y;
   const int ks_per = K / 16;
-  const int steps = ks_per / (NW * ksplit);
   const int k0 = (ks * NW + wave) * steps;
   const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * ks_per + k0) * 64 + lane;
   const bf16_t* xp[RB];
@@ -253,8 +254,8 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
   dim3 grid(n_blocks, ksplit);
 #define TTASR_SKINNY(NW_, RB_, U_, ONE_)                                                                                              \
   do {                                                                                                                                \
-    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride); \
-    else hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, e, slab, slab_stride); \
+    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
   } while (0)
 #define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
   do {                                                                             \
