@@ -187,6 +187,10 @@ template <typename T> void launch_enc_attn_simple(const T* qkv, T* out, int B, i
 void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s);
 
 // decoder
+// The rule scalars that change from one 30-s window to the next (prompt geometry with condition_on_previous_text, the token
+// budget, the seed of a fallback attempt).  select_kernel reads them from device memory, so the captured decode-step graphs
+// survive the change (everything else in RuleParams is baked into the captured launch).
+struct RuleDyn { int32_t max_prompt, max_new, sot_index; uint32_t seed; };
 struct DecState {            // device-resident per-row search state
   int32_t* cur_tok;          // [B] token fed at this step
   int32_t* step;             // [1] position of cur_tok
@@ -202,6 +206,7 @@ struct DecState {            // device-resident per-row search state
   const int32_t* prompt;     // [B][max_prompt]
   const int32_t* prompt_len; // [B]
   const uint8_t* mask;       // [V] bit0 suppress, bit1 begin-suppress
+  const RuleDyn* dyn;        // [1] overrides RuleParams.{max_prompt, max_new, sot_index, seed} in select_kernel
 };
 struct RuleParams {
   int V, ldv, max_prompt, max_new;
@@ -230,7 +235,9 @@ template <typename T>
 void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B / kv_div][H][Tk][64]*/, T* out, int B, int H,
                               int Tk, int kv_div, hipStream_t s,
                               float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/,
-                              SlabIn sq = SlabIn{} /*q from K-split partial tiles*/);
+                              SlabIn sq = SlabIn{} /*q from K-split partial tiles*/,
+                              int ws_rows = 0 /*rows the workspace was sized for (0: B); rows that share a clip (kv_div 2..8)
+                                                are served by one K/V stream per clip when they fit*/);
 extern int g_skinny_nt;     // TTASR_W_NT: nontemporal weight loads in the decode GEMMs (A/B experiments)
 extern int g_xattn_variant;  // TTASR_XATTN: cross-attention kernel variant (A/B experiments)
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the

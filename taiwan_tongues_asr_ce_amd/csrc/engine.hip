@@ -97,6 +97,7 @@ struct ttasr_ctx {
   int prefill_ns_min = 16;    // TTASR_PREFILL_NS_MIN: shortest prompt whose sot position is taken from the prefill pass
   bool enc_res_epilogue = false;  // TTASR_ENC_RES_EPI: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
+  RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
   int max_new_alloc = 0, max_prompt_alloc = 0;
 
@@ -337,6 +338,8 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(dalloc(c, &c->st.no_speech, B * 4)); TRY(dalloc(c, &c->st.out_tokens, (size_t)B * c->max_new_alloc * 4));
   TRY(dalloc(c, &c->prompt_dev, (size_t)B * c->max_prompt_alloc * 4)); TRY(dalloc(c, &c->plen_dev, B * 4));
   TRY(dalloc(c, &c->mask_dev, (size_t)c->V + 16));
+  TRY(dalloc(c, &c->rule_dyn_dev, sizeof(RuleDyn)));
+  c->st.dyn = c->rule_dyn_dev;
   TRY(dalloc(c, &c->pairs_dev, (size_t)B * 2 * 4));
   TRY(dalloc(c, &c->topk_lp, (size_t)B * 8 * 4)); TRY(dalloc(c, &c->topk_id, (size_t)B * 8 * 4));
   TRY(dalloc(c, &c->row_state, (size_t)B * 4 * 4));
@@ -553,7 +556,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
     if (!(c->skip_mask & 8))
       launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq);
+                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq, c->maxB - row0);
     residual_gemm(datt, L.wox, L.wox_sh, L.box, d, 0);
     ln(L.ln3g, L.ln3b);
     { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; dec_gemm<T>(c, g, L.w1_sh); }
@@ -608,7 +611,8 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
       launch_cross_attn_probs<T>((const T*)qkv, Kc, Kc + c->xkv_which_elems, (T*)att, n, c->H, c->T, al->sel + (size_t)l * c->H,
                                  al->probs, s);
     } else {
-      launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s);
+      launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s,
+                                  (c->no_xsplit || npos * seq_per_clip > 8) ? nullptr : c->xsplit_ws, SlabIn{}, c->maxB);
     }
     { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
     launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);
@@ -710,6 +714,18 @@ int upload_rules(ttasr_ctx* c, const ttasr_gen_opts* o, int max_prompt) {
   rp.temperature = 0.f; rp.seed = 0;
   if (rp.eot < 0 || rp.eot >= c->V || rp.timestamp_begin < 0 || rp.timestamp_begin > c->V)
     return fail(c, TTASR_E_INVALID, "special token ids outside vocabulary");
+  return 0;
+}
+
+void drop_rule_graphs(ttasr_ctx* c);
+// After the rules of a call are known: the per-window scalars go to device memory (stream-ordered in front of the decode
+// launches); the captured mode 0 / 2 graphs are dropped only when a BAKED scalar changed.
+int commit_rules(ttasr_ctx* c, const RuleParams& old) {
+  c->rule_dyn_host = RuleDyn{c->rp.max_prompt, c->rp.max_new, c->rp.sot_index, c->rp.seed};
+  HIPCHK(c, hipMemcpyAsync(c->rule_dyn_dev, &c->rule_dyn_host, sizeof(RuleDyn), hipMemcpyHostToDevice, c->stream));
+  RuleParams a = old;
+  a.max_prompt = c->rp.max_prompt; a.max_new = c->rp.max_new; a.sot_index = c->rp.sot_index; a.seed = c->rp.seed;
+  if (memcmp(&a, &c->rp, sizeof a) != 0) drop_rule_graphs(c);
   return 0;
 }
 
@@ -1113,7 +1129,7 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   RuleParams old = c->rp;
   TRY(upload_rules(c, o, max_prompt));
   c->rp.temperature = temperature; c->rp.seed = seed;
-  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_rule_graphs(c);  // rule scalars are baked into the captured launches
+  TRY(commit_rules(c, old));
   TRY(reset_search(c, R));
   hipStream_t s = c->stream;
   std::vector<int32_t> pr((size_t)R * max_prompt, 0), pl(R);
@@ -1236,7 +1252,7 @@ static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t
   auto sot_of = [&](int a) { return sots ? sots[a] : o->sot_index; };
   RuleParams old_rp = c->rp;
   TRY(upload_rules(c, o, max_prompt));
-  if (memcmp(&old_rp, &c->rp, sizeof old_rp) != 0) drop_rule_graphs(c);
+  TRY(commit_rules(c, old_rp));
   TRY(reset_search(c, R));
   c->st.prompt = nullptr; c->st.prompt_len = nullptr;
   c->B_dec = R;
@@ -1454,7 +1470,7 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   ttasr_gen_opts oo = *o;
   oo.max_new_tokens = std::max(1, std::min(oo.max_new_tokens, c->max_new_alloc));
   TRY(upload_rules(c, &oo, 1));
-  if (memcmp(&old, &c->rp, sizeof old) != 0) drop_rule_graphs(c);
+  TRY(commit_rules(c, old));
   TRY(reset_search(c, n));
   std::vector<int32_t> ns(n), last(n, -1), pen(n, -1), lts(n, -1);
   for (int r = 0; r < n; ++r) {
@@ -1475,6 +1491,8 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   if (!c->rows_out) TRY(dalloc(c, &c->rows_out, (size_t)c->maxB * c->V * 4));
   DecState st = c->st; st.prompt = nullptr; st.prompt_len = nullptr;
   RuleParams rp = c->rp; rp.max_new = c->max_new_alloc;  // histories may be longer than opts.max_new_tokens
+  c->rule_dyn_host.max_new = rp.max_new;
+  HIPCHK(c, hipMemcpyAsync(c->rule_dyn_dev, &c->rule_dyn_host, sizeof(RuleDyn), hipMemcpyHostToDevice, s));
   launch_select(c->logits, st, rp, n, c->rows_out, s, nullptr, 0);
   HIPCHK(c, hipMemcpyAsync(out_rows, c->rows_out, (size_t)n * c->V * 4, hipMemcpyDeviceToHost, s));
   if (out_choice) HIPCHK(c, hipMemcpyAsync(out_choice, c->st.cur_tok, n * 4, hipMemcpyDeviceToHost, s));
@@ -1628,6 +1646,18 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
                                            (float*)c->datt, B, c->H, c->T, 1, s);
       bytes = (double)B * (2.0 * T_ * d + 2.0 * d) * e; flops = (double)B * 4.0 * T_ * d;
+    } else if (k == "xattn_beam5" || k == "xattn_beam5_rows") {
+      // B rows = B / 5 clips x 5 hypotheses sharing their clip's cross-KV: one stream per clip ("xattn_beam5") or the
+      // one-workgroup-per-row kernel ("xattn_beam5_rows")
+      if (B % 5) return fail(c, TTASR_E_INVALID, "xattn_beam5 needs a multiple of 5 rows");
+      static int layer_rr2 = 0;
+      const char* Kx = (const char*)c->xkv + (size_t)(layer_rr2++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
+      float* ws = k == "xattn_beam5" ? c->xsplit_ws : nullptr;
+      if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
+                                                    (bf16_t*)c->datt, B, c->H, c->T, 5, s, ws, SlabIn{}, c->maxB);
+      else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
+                                           (float*)c->datt, B, c->H, c->T, 5, s, ws, SlabIn{}, c->maxB);
+      bytes = (double)(B / 5) * 2.0 * T_ * d * e + (double)B * 2.0 * d * e; flops = (double)B * 4.0 * T_ * d;
     } else if (k == "enc_gemm_fc1") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].w1; g.M = B * c->T; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->enc[0].b1; g.epi.act = 1; g.epi.out_t = c->mid;

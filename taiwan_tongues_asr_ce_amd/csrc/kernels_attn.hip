@@ -597,6 +597,132 @@ __global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __res
   out[((int64_t)b * H + h) * 64 + tid] = from_f<T>(num / den);
 }
 
+// Rows that share a clip's cross-KV (the `kv_div` hypotheses of a beam, or the prompt positions of a prefill pass) in ONE
+// workgroup per (clip, head, frame slice): K and V are streamed ONCE for all NQ queries instead of once per row - the per-row
+// kernels above re-read the same 384 KB per (clip, head) NQ times (the Infinity Cache removes the HBM traffic, not the
+// CU-side ingest that bounds the kernel).  Same slice protocol as cross_attn_split_kernel: every (row, slice) leaves
+// {max, sum, unnormalised out[64]} for cross_attn_merge_kernel; rows of clip a are a*NQ .. a*NQ + NQ - 1.
+template <typename T, int NQ>
+__global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict__ q, const T* __restrict__ K, const T* __restrict__ V,
+                                                            int H, int Tk, int chunk, float* __restrict__ ws, SlabIn sq) {
+  constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
+  constexpr int UNROLL = NQ <= 4 ? 8 : 4;
+  extern __shared__ float sc[];  // [NQ][chunk] scores, then [4][NQ][64] partial outputs, [2][NQ][4] reductions
+  const int a = blockIdx.y, h = blockIdx.x, z = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = H * 64;
+  const int sub = lane % LPR, rin = lane / LPR;
+  float* part = sc + NQ * chunk;
+  float* red = part + 4 * NQ * 64;
+  const int t0 = z * chunk, n = min(chunk, Tk - t0);  // this slice: frames t0 .. t0+n-1 (n >= 1 by construction)
+  const T* Kp = K + (((int64_t)a * H + h) * Tk + t0) * 64;
+  const T* Vp = V + (((int64_t)a * H + h) * Tk + t0) * 64;
+  const int n_it = (n + 4 * RPI - 1) / (4 * RPI);
+  float kv[UNROLL][VEC];
+  auto load_rows = [&](const T* base, int it0) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      RowVec<T>::load(base + (int64_t)min(t, n - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
+    }
+  };
+  load_rows(Kp, 0);  // the stream starts before the queries are fetched
+  float qv[NQ][VEC];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const int64_t off = (int64_t)(a * NQ + qi) * d + h * 64 + sub * VEC;
+    if (sq.n > 0) load_row_slabs<T>(sq, off, h * 64 + sub * VEC, qv[qi]);
+    else RowVec<T>::load(q + off, qv[qi]);
+  }
+  float mloc[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) mloc[qi] = -1e30f;
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    if (it0 > 0) load_rows(Kp, it0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s = fmaf(qv[qi][j], kv[u][j], s);
+        s = group_reduce<LPR>(s, OpSum{});
+        if (t < n) {
+          if (sub == 0) sc[qi * chunk + t] = s;
+          mloc[qi] = fmaxf(mloc[qi], s);
+        }
+      }
+    }
+  }
+  load_rows(Vp, 0);  // V rows do not depend on the softmax: requested before it
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float m = wave_max(mloc[qi]);
+    if (lane == 0) red[qi * 4 + wave] = m;
+  }
+  __syncthreads();
+  float mx[NQ], lsum[NQ];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    mx[qi] = fmaxf(fmaxf(red[qi * 4], red[qi * 4 + 1]), fmaxf(red[qi * 4 + 2], red[qi * 4 + 3]));
+    lsum[qi] = 0.f;
+  }
+  for (int t = tid; t < n; t += 256) {
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) {
+      const float p = __expf(sc[qi * chunk + t] - mx[qi]);
+      sc[qi * chunk + t] = p;
+      lsum[qi] += p;
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+    const float l = wave_sum(lsum[qi]);
+    if (lane == 0) red[NQ * 4 + qi * 4 + wave] = l;
+  }
+  __syncthreads();
+  float acc[NQ][VEC];
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[qi][j] = 0.f;
+  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
+    if (it0 > 0) load_rows(Vp, it0);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      if (t < n) {
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          const float p = sc[qi * chunk + t];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[qi][j] = fmaf(p, kv[u][j], acc[qi][j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < NQ; ++qi) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[qi][j] = stride_reduce<LPR>(acc[qi][j], OpSum{});
+    if (rin == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) part[(wave * NQ + qi) * 64 + sub * VEC + j] = acc[qi][j];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NQ * 64; i += 256) {
+    const int qi = i >> 6, c = i & 63;
+    float* mine = ws + ((int64_t)((a * NQ + qi) * H + h) * S + z) * 66;
+    mine[2 + c] = (part[(0 * NQ + qi) * 64 + c] + part[(1 * NQ + qi) * 64 + c]) + (part[(2 * NQ + qi) * 64 + c] + part[(3 * NQ + qi) * 64 + c]);
+    if (c == 0) {
+      mine[0] = mx[qi];  // every thread holds every query's maximum; the sums come from the second reduction
+      mine[1] = (red[NQ * 4 + qi * 4] + red[NQ * 4 + qi * 4 + 1]) + (red[NQ * 4 + qi * 4 + 2] + red[NQ * 4 + qi * 4 + 3]);
+    }
+  }
+}
+
 int cross_attn_splits(int B, int H, int Tk) {
   const int bh = B * H;
   if (bh >= 256) return 1;
@@ -608,8 +734,30 @@ int cross_attn_splits(int B, int H, int Tk) {
 
 template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
-                              float* split_ws, SlabIn sq) {
-  const int S = split_ws ? cross_attn_splits(B, H, Tk) : 1;
+                              float* split_ws, SlabIn sq, int ws_rows) {
+  if (ws_rows <= 0) ws_rows = B;  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
+  // rows sharing a clip (beam hypotheses, prefill positions): one K/V stream per clip for all of them.  Measured at beam 5
+  // (kernel + merge): 30 rows 18.9 us against 27.9 us for one workgroup per row (39.3 us when the rows do not share); below
+  // 256 (row, head) items the frame-split per-row kernels fill the chip better (5 rows: 9.5 vs 11.8 us) and keep the job.
+  if (split_ws && kv_div >= 2 && kv_div <= 8 && B % kv_div == 0 && B * H >= 256) {
+    const int A = B / kv_div;
+    const int Sq = cross_attn_splits(A, H, Tk);
+    const int chunk = ((Tk + Sq - 1) / Sq + 31) / 32 * 32;
+    const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty; S2 <= 8
+    const size_t lds = sizeof(float) * ((size_t)kv_div * chunk + 4 * kv_div * 64 + 8 * kv_div);
+    if (lds <= 64 * 1024 && (int64_t)B * S2 <= (int64_t)ws_rows * 8) {
+      const dim3 grid(H, A, S2);
+#define TTASR_MQ(NQ_) hipLaunchKernelGGL((cross_attn_mq_kernel<T, NQ_>), grid, dim3(256), lds, s, q, K, V, H, Tk, chunk, split_ws, sq)
+      switch (kv_div) {
+        case 2: TTASR_MQ(2); break; case 3: TTASR_MQ(3); break; case 4: TTASR_MQ(4); break; case 5: TTASR_MQ(5); break;
+        case 6: TTASR_MQ(6); break; case 7: TTASR_MQ(7); break; default: TTASR_MQ(8); break;
+      }
+#undef TTASR_MQ
+      hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
+      return;
+    }
+  }
+  const int S = (split_ws && B <= ws_rows) ? cross_attn_splits(B, H, Tk) : 1;
   if (S > 1) {
     int chunk = ((Tk + S - 1) / S + 31) / 32 * 32;
     const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty
@@ -643,6 +791,6 @@ template void launch_cross_attn_probs<float>(const float*, const float*, const f
 template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, const int*, float*,
                                               hipStream_t);
 template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*,
-                                              SlabIn);
+                                              SlabIn, int);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
-                                               float*, SlabIn);
+                                               float*, SlabIn, int);

@@ -201,10 +201,10 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
   st.last_tok = sgpr_pin_ptr(st.last_tok); st.pen_tok = sgpr_pin_ptr(st.pen_tok); st.last_ts = sgpr_pin_ptr(st.last_ts);
   st.done = sgpr_pin_ptr(st.done); st.n_done = sgpr_pin_ptr(st.n_done); st.sum_logprob = sgpr_pin_ptr(st.sum_logprob);
   st.no_speech = sgpr_pin_ptr(st.no_speech); st.out_tokens = sgpr_pin_ptr(st.out_tokens); st.prompt = sgpr_pin_ptr(st.prompt);
-  st.prompt_len = sgpr_pin_ptr(st.prompt_len); st.mask = sgpr_pin_ptr(st.mask);
-  p.V = sgpr_pin(p.V); p.ldv = sgpr_pin(p.ldv); p.max_prompt = sgpr_pin(p.max_prompt); p.max_new = sgpr_pin(p.max_new);
+  st.prompt_len = sgpr_pin_ptr(st.prompt_len); st.mask = sgpr_pin_ptr(st.mask); st.dyn = sgpr_pin_ptr(st.dyn);
+  p.V = sgpr_pin(p.V); p.ldv = sgpr_pin(p.ldv);
   p.eot = sgpr_pin(p.eot); p.no_timestamps = sgpr_pin(p.no_timestamps); p.timestamp_begin = sgpr_pin(p.timestamp_begin);
-  p.no_speech = sgpr_pin(p.no_speech); p.sot_index = sgpr_pin(p.sot_index); p.timestamps = sgpr_pin(p.timestamps);
+  p.no_speech = sgpr_pin(p.no_speech); p.timestamps = sgpr_pin(p.timestamps);
   p.max_initial = sgpr_pin(p.max_initial); p.suppress_eot = sgpr_pin(p.suppress_eot);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (int64_t)b * p.ldv;
@@ -218,7 +218,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
   r.n = st.n_sampled[b];
   const int last = st.last_tok[b], pen = st.pen_tok[b], lts = st.last_ts[b], done_b = st.done[b];
   const float slp = st.sum_logprob[b];
+  const RuleDyn dyn = *st.dyn;  // the per-window rule scalars (the by-value copies in `p` are those of the capture)
   __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first use below
+  p.max_prompt = dyn.max_prompt; p.max_new = dyn.max_new; p.sot_index = dyn.sot_index; p.seed = dyn.seed;
   const int plen = st.prompt_len ? plen_raw : 1;
 
   const bool forced = st.prompt && (step + 1 < plen);

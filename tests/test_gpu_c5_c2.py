@@ -1,5 +1,5 @@
 """GPU coverage of BASELINE.json configs C5 (beam 5 + streaming at whisper-large-v3 geometry) and C2 (whisper-small, bf16, batch 8):
-  * beam 5 at large-v3 WIDTH (d 1280, 20 heads, V 51866, 2 + 2 layers so the oracle can follow): 2 clips x 5 hypotheses share
+  * beam 5 at large-v3 WIDTH (d 1280, 20 heads, V 51866, 2 + 2 layers so the oracle can follow): 3 clips x 5 hypotheses share
     their clip's cross-KV (kv_div = 5), ragged prompts (one clip carries a previous-text prompt), against R.beam_decode -
     itself pinned to HF generate(num_beams=5) (tests/golden/beam_hf.npz) and to a hand-built known answer
     (tests/test_oracle_golden.py);
@@ -28,14 +28,17 @@ def test_beam5_at_large_v3_width_with_ragged_prompts_matches_oracle():
     dims = PRESETS["large-v3-w2"]
     rd = R.Dims(**dims.as_dict())
     sd = synth.state_dict(dims)
-    clips = [synth.noise_clip(0), synth.tonal_clip(1)]
-    e = Engine(dims, COMPUTE_F32, 10)
+    # 3 clips x 5 hypotheses x 20 heads = 300 (row, head) items: past 256 the hypotheses of a clip are served by ONE K/V stream
+    # per (clip, head, frame slice) (kernels_attn.hip cross_attn_mq_kernel) - this test is its f32 parity check
+    clips = [synth.noise_clip(0), synth.tonal_clip(1), synth.noise_clip(2)]
+    e = Engine(dims, COMPUTE_F32, 15)
     e.load_weights(sd.items())
     st = e.special
     e.log_mel(clips, want_output=False)
-    e.encode(2)
-    prompts = [[st.sot_prev, 1000, 2000, 3000, 4000, 5000, st.sot, st.lang_zh, st.transcribe], [st.sot, st.lang_zh, st.transcribe]]
-    sots = [6, 0]
+    e.encode(3)
+    prompts = [[st.sot_prev, 1000, 2000, 3000, 4000, 5000, st.sot, st.lang_zh, st.transcribe], [st.sot, st.lang_zh, st.transcribe],
+               [st.sot_prev, 1234, st.sot, st.lang_zh, st.transcribe]]
+    sots = [6, 0, 2]
     opts = e.gen_opts(8, True)
     res = e.generate_beam(prompts, 5, opts, sot_index=sots)
     again = e.generate_beam(prompts, 5, opts, sot_index=sots)
@@ -46,7 +49,7 @@ def test_beam5_at_large_v3_width_with_ragged_prompts_matches_oracle():
     enc = R.encoder_forward(mel, W, rd)
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
-    for a in range(2):
+    for a in range(3):
         ref = R.beam_decode(enc[a:a + 1], prompts[a], W, rd, rules, 5, 8, no_speech_token=st.no_speech, sot_index=sots[a])
         assert res.tokens[a] == ref.tokens[0], a
         assert abs(float(res.sum_logprob[a]) - ref.sum_logprob[0]) < 5e-3

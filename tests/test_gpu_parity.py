@@ -262,6 +262,37 @@ def test_ragged_prompts_and_lengths(eng_tiny_f32, tiny_oracle):
         assert abs(float(res.sum_logprob[b]) - ref.sum_logprob[0]) < 2e-2
 
 
+def test_window_to_window_rule_changes_reuse_the_captured_step(eng_tiny_f32, tiny_oracle):
+    """With condition_on_previous_text the prompt length, the position of <|startoftranscript|> (where the no-speech
+    probability is taken) and the token budget change from one 30-s window to the next; a fallback attempt changes the seed.
+    select_kernel reads those four scalars from device memory (common.hpp RuleDyn) so that the captured decode-step graphs are
+    kept: calls with different geometry interleaved on ONE engine must each equal the oracle, in any order and repeatedly."""
+    dims, W, clips, enc_ref = tiny_oracle
+    e = eng_tiny_f32
+    st = e.special
+    e.log_mel(clips, want_output=False)
+    e.encode(4)
+    calls = [  # (prompt, sot_index, max_new)
+        ([st.sot, st.lang_zh, st.transcribe], 0, 9),
+        ([st.sot_prev, 1000, 1001, 1002, st.sot, st.lang_zh, st.transcribe], 4, 5),
+        ([st.sot_prev] + list(range(2000, 2010)) + [st.sot, st.lang_zh, st.transcribe], 11, 12),
+    ]
+    def oracle(prompt, sot_index, max_new, b):
+        o = e.gen_opts(max_new, True, sot_index=sot_index)
+        rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                        suppress=[o.suppress[i] for i in range(o.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
+        return R.greedy_decode(enc_ref[b:b + 1], prompt, W, dims, rules, max_new, no_speech_token=st.no_speech, sot_index=sot_index)
+    refs = [[oracle(p, si, mn, b) for b in range(4)] for p, si, mn in calls]
+    for order in ([0, 1, 2], [2, 0, 1, 1, 0, 2]):
+        for ci in order:
+            p, si, mn = calls[ci]
+            res = e.generate([p] * 4, e.gen_opts(mn, True, sot_index=si))
+            for b in range(4):
+                assert res.tokens[b] == refs[ci][b].tokens[0], (ci, b)
+                assert abs(float(res.sum_logprob[b]) - refs[ci][b].sum_logprob[0]) < 2e-2
+                assert abs(float(res.no_speech_prob[b]) - refs[ci][b].no_speech_prob[0]) < 1e-3 * max(refs[ci][b].no_speech_prob[0], 1e-6) + 1e-6
+
+
 def test_api_misuse_is_an_error_not_a_crash(eng_tiny_f32):
     from taiwan_tongues_asr_ce_amd.engine import TtasrError
     e = eng_tiny_f32

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Beam-search decode time on one GPU (large-v3 geometry, bf16): A clips x beam hypotheses, short prompt, N new tokens.
+One JSON line per configuration; TTASR_NO_XSPLIT=1 in the environment selects the one-workgroup-per-row cross-attention.
+
+    python tools/beam_step_bench.py [--clips 6] [--beam 5] [--new-tokens 32]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--clips", default="1,6")
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--new-tokens", type=int, default=32)
+    args = ap.parse_args()
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+
+    dims = PRESETS[args.model]
+    weights = list(synth.iter_weights(dims))
+    for A in [int(x) for x in args.clips.split(",")]:
+        e = Engine(dims, COMPUTE_BF16, A * args.beam)
+        e.load_weights(weights)
+        st = e.special
+        e.log_mel([synth.noise_clip(b) for b in range(A)], want_output=False)
+        e.encode(A)
+        prompt = [st.sot, st.lang_zh, st.transcribe]
+        opts = e.gen_opts(args.new_tokens, True)
+        ms, toks = [], None
+        for _ in range(4):
+            t0 = time.perf_counter()
+            r = e.generate_beam([prompt] * A, args.beam, opts)
+            ms.append((time.perf_counter() - t0) * 1e3)
+            assert toks is None or r.tokens == toks
+            toks = r.tokens
+        n_steps = max(len(t) for t in toks) + len(prompt)
+        print(json.dumps({"clips": A, "beam": args.beam, "rows": A * args.beam, "wall_ms": round(min(ms[1:]), 2),
+                          "steps_upper_bound": n_steps, "ms_per_step": round(min(ms[1:]) / n_steps, 3),
+                          "no_xsplit": bool(os.environ.get("TTASR_NO_XSPLIT"))}), flush=True)
+        e.close()
+
+
+if __name__ == "__main__":
+    main()
