@@ -105,6 +105,7 @@ struct ttasr_ctx {
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
   bool no_xsplit = false;   // TTASR_NO_XSPLIT: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // TTASR_NO_PREFILL: feed prompts token by token (A/B testing)
+  bool prefill_tiled = false;  // TTASR_PREFILL_TILED: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
   hipEvent_t ev[8]{};
   float phase_ms[4]{0, 0, 0, 0};
 
@@ -596,15 +597,24 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
   float* x = c->x;
   void *h = c->h, *qkv = c->qkv, *att = c->att, *mid = c->mid;
   launch_embed_prefill<T>(c->prompt_dev, max_prompt, 1, n_seq, npos, (const T*)c->emb, (const T*)c->dpos, x, d, s);
+  // up to 128 rows (short prompts: a handful of positions x the clips of a pass) the fragment-packed decode GEMM streams each
+  // weight once for all rows; beyond that the rows are a real M dimension for the tiled encoder GEMMs
+  const bool small = n <= 128 && !c->force_basic && !c->prefill_tiled;
+  auto pgemm = [&](const GemmArgs& g, const void* Wsh) {
+    if constexpr (sizeof(T) == 2) {
+      if (small && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, s)) return;
+    }
+    gemm<T>(c, g);
+  };
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
     launch_layernorm<T>(x, L.ln1g, L.ln1b, (T*)h, n, d, s);
-    { GemmArgs g = lin_args<T>(h, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = qkv; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(h, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = qkv; pgemm(g, L.wqkv_sh); }
     launch_self_attn_prefill<T>((const T*)qkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
                                 c->identity_pages, (T*)att, n_seq, npos, c->H, s);
-    { GemmArgs g = lin_args<T>(att, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(att, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.wo_sh); }
     launch_layernorm<T>(x, L.ln2g, L.ln2b, (T*)h, n, d, s);
-    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = qkv; gemm<T>(c, g); }  // q reuses the qkv buffer
+    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = qkv; pgemm(g, L.wqx_sh); }  // q reuses the qkv buffer
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
     if (al) {
       const T* Kc = Kx + (int64_t)al->clip * c->H * c->T * 64;
@@ -614,10 +624,10 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
       launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s,
                                   (c->no_xsplit || npos * seq_per_clip > 8) ? nullptr : c->xsplit_ws, SlabIn{}, c->maxB);
     }
-    { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.wox_sh); }
     launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);
-    { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; gemm<T>(c, g); }
-    { GemmArgs g = lin_args<T>(mid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = x; g.epi.out_f32 = x; gemm<T>(c, g); }
+    { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; pgemm(g, L.w1_sh); }
+    { GemmArgs g = lin_args<T>(mid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.w2_sh); }
   }
 }
 
@@ -819,6 +829,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
   c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
   c->no_prefill = getenv("TTASR_NO_PREFILL") != nullptr;
+  c->prefill_tiled = getenv("TTASR_PREFILL_TILED") != nullptr;
   c->no_xsplit = getenv("TTASR_NO_XSPLIT") != nullptr;
 #ifdef TTASR_EXPERIMENTS
   if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
