@@ -1,18 +1,4 @@
 set -x
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r3h; mkdir -p $O
-export TMPDIR=/tmp
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
-timeout 600 python bench.py --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-cat $O/bench.json | head -c 700; tail -3 $O/bench.err
-cp profiles/bench_tokens_crc.json $O/
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
-f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -3 $O/kernel_stats.csv | cut -c1-250; rm -rf $O/prof
-for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
-  tag=$(echo $p | cut -d' ' -f1)
-  timeout 900 rocprofv3 --pmc $p --output-format csv -d $O/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
-done
-python tools/microbench/pmc_report.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES r2 $O > $O/pmc_report.txt 2>&1; tail -3 $O/pmc_report.txt
-cat $O/xattn_pmc.json
-find $O -name "*counter_collection.csv" -delete; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
-timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_g2.json 2> $O/bench_g2.err; echo "bench g2 rc=$?"; cat $O/bench_g2.json | head -c 500
+O=$GRAFT_REPO_ROOT/gpurun_out/r3i; mkdir -p $O
+for r in 30 60; do timeout 600 python tools/folder_bench.py large-v3 $r > $O/folder_$r.txt 2>&1; tail -1 $O/folder_$r.txt; done
