@@ -58,9 +58,6 @@ __device__ __forceinline__ bool masked_mk(uint32_t mk, int i, const RowRanges& q
   return ((mk & q.n0mask) != 0) | (i == q.x_eot) | (i == q.x_nots) | !(in_txt | in_ts);
 }
 
-__device__ __forceinline__ bool masked(int i, const RowRanges& q, const uint8_t* __restrict__ mask) {
-  return masked_mk(mask[i], i, q);
-}
 // A logits row lives in REGISTERS for the whole kernel: with 1024 threads every Whisper vocabulary (51 864 .. 51 866 <= 13 x 4096)
 // is 13 float4 + 13 mask words per thread, all requested back to back - ONE memory round trip instead of one per loop
 // iteration and per pass.  Thread t holds elements 4t..4t+3, 4(t+1024).. (chunk k = elements [4096 k, 4096 k + 4095]); the < 4
