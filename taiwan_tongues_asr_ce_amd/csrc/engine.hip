@@ -622,7 +622,7 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
                                  al->probs, s);
     } else {
       launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s,
-                                  (c->no_xsplit || npos * seq_per_clip > 8) ? nullptr : c->xsplit_ws, SlabIn{}, c->maxB);
+                                  c->no_xsplit ? nullptr : c->xsplit_ws, SlabIn{}, c->maxB);
     }
     { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.wox_sh); }
     launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);

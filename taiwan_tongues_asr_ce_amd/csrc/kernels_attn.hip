@@ -602,21 +602,29 @@ __global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __res
 // kernels above re-read the same 384 KB per (clip, head) NQ times (the Infinity Cache removes the HBM traffic, not the
 // CU-side ingest that bounds the kernel).  Same slice protocol as cross_attn_split_kernel: every (row, slice) leaves
 // {max, sum, unnormalised out[64]} for cross_attn_merge_kernel; rows of clip a are a*NQ .. a*NQ + NQ - 1.
+// A clip's kv_div rows are cut into `groups` workgroup-rows of NQ consecutive rows (the last one holds nq_last <= NQ): prompts
+// longer than 8 positions re-stream the clip's K/V once per 8 positions instead of once per position.  With a single frame
+// slice (gridDim.z == 1: enough (group, head) items to fill the chip) the result is normalised and stored directly (`out`),
+// without the workspace and the merge launch.
 template <typename T, int NQ>
 __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict__ q, const T* __restrict__ K, const T* __restrict__ V,
-                                                            int H, int Tk, int chunk, float* __restrict__ ws, SlabIn sq) {
+                                                            int H, int Tk, int chunk, float* __restrict__ ws, SlabIn sq,
+                                                            int kv_div, int groups, int nq_last, T* __restrict__ out) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = NQ <= 4 ? 8 : 4;
   extern __shared__ float sc[];  // [NQ][chunk] scores, then [4][NQ][64] partial outputs, [2][NQ][4] reductions
-  const int a = blockIdx.y, h = blockIdx.x, z = blockIdx.z, S = gridDim.z;
+  const int h = blockIdx.x, z = blockIdx.z, S = gridDim.z;
+  const int clip = blockIdx.y / groups, grp = blockIdx.y - clip * groups;
+  const int row0 = clip * kv_div + grp * NQ;                 // first row of this group
+  const int nq = grp == groups - 1 ? nq_last : NQ;           // valid rows in it (uniform)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + NQ * chunk;
   float* red = part + 4 * NQ * 64;
   const int t0 = z * chunk, n = min(chunk, Tk - t0);  // this slice: frames t0 .. t0+n-1 (n >= 1 by construction)
-  const T* Kp = K + (((int64_t)a * H + h) * Tk + t0) * 64;
-  const T* Vp = V + (((int64_t)a * H + h) * Tk + t0) * 64;
+  const T* Kp = K + (((int64_t)clip * H + h) * Tk + t0) * 64;
+  const T* Vp = V + (((int64_t)clip * H + h) * Tk + t0) * 64;
   const int n_it = (n + 4 * RPI - 1) / (4 * RPI);
   float kv[UNROLL][VEC];
   auto load_rows = [&](const T* base, int it0) {
@@ -630,7 +638,7 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   float qv[NQ][VEC];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
-    const int64_t off = (int64_t)(a * NQ + qi) * d + h * 64 + sub * VEC;
+    const int64_t off = (int64_t)(row0 + min(qi, nq - 1)) * d + h * 64 + sub * VEC;  // rows past nq_last: a valid row, result dropped
     if (sq.n > 0) load_row_slabs<T>(sq, off, h * 64 + sub * VEC, qv[qi]);
     else RowVec<T>::load(q + off, qv[qi]);
   }
@@ -714,12 +722,16 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   __syncthreads();
   for (int i = tid; i < NQ * 64; i += 256) {
     const int qi = i >> 6, c = i & 63;
-    float* mine = ws + ((int64_t)((a * NQ + qi) * H + h) * S + z) * 66;
-    mine[2 + c] = (part[(0 * NQ + qi) * 64 + c] + part[(1 * NQ + qi) * 64 + c]) + (part[(2 * NQ + qi) * 64 + c] + part[(3 * NQ + qi) * 64 + c]);
-    if (c == 0) {
-      mine[0] = mx[qi];  // every thread holds every query's maximum; the sums come from the second reduction
-      mine[1] = (red[NQ * 4 + qi * 4] + red[NQ * 4 + qi * 4 + 1]) + (red[NQ * 4 + qi * 4 + 2] + red[NQ * 4 + qi * 4 + 3]);
+    if (qi >= nq) continue;
+    const float acc_c = (part[(0 * NQ + qi) * 64 + c] + part[(1 * NQ + qi) * 64 + c]) + (part[(2 * NQ + qi) * 64 + c] + part[(3 * NQ + qi) * 64 + c]);
+    const float lsl = (red[NQ * 4 + qi * 4] + red[NQ * 4 + qi * 4 + 1]) + (red[NQ * 4 + qi * 4 + 2] + red[NQ * 4 + qi * 4 + 3]);
+    if (S == 1) {  // the only slice: finished here
+      out[(int64_t)(row0 + qi) * d + h * 64 + c] = from_f<T>(acc_c / lsl);
+      continue;
     }
+    float* mine = ws + ((int64_t)((row0 + qi) * H + h) * S + z) * 66;
+    mine[2 + c] = acc_c;
+    if (c == 0) { mine[0] = mx[qi]; mine[1] = lsl; }  // every thread holds every query's maximum
   }
 }
 
@@ -736,24 +748,28 @@ template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
                               float* split_ws, SlabIn sq, int ws_rows) {
   if (ws_rows <= 0) ws_rows = B;  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
-  // rows sharing a clip (beam hypotheses, prefill positions): one K/V stream per clip for all of them.  Measured at beam 5
-  // (kernel + merge): 30 rows 18.9 us against 27.9 us for one workgroup per row (39.3 us when the rows do not share); below
-  // 256 (row, head) items the frame-split per-row kernels fill the chip better (5 rows: 9.5 vs 11.8 us) and keep the job.
-  if (split_ws && kv_div >= 2 && kv_div <= 8 && B % kv_div == 0 && B * H >= 256) {
+  // rows sharing a clip (beam hypotheses, prefill positions): one K/V stream per (clip, group of <= 8 rows) for all of them.
+  // Measured at beam 5 (kernel + merge): 30 rows 18.9 us against 27.9 us for one workgroup per row (39.3 us when the rows do
+  // not share); below 256 (row, head) items the frame-split per-row kernels fill the chip better (5 rows: 9.5 vs 11.8 us) and
+  // keep the job.
+  if (split_ws && kv_div >= 2 && B % kv_div == 0 && B * H >= 256) {  // split_ws == nullptr: the caller asked for per-row kernels
     const int A = B / kv_div;
-    const int Sq = cross_attn_splits(A, H, Tk);
+    const int NQ = kv_div < 8 ? kv_div : 8, groups = (kv_div + NQ - 1) / NQ, nq_last = kv_div - (groups - 1) * NQ;
+    const int Sq = cross_attn_splits(A * groups, H, Tk);
     const int chunk = ((Tk + Sq - 1) / Sq + 31) / 32 * 32;
     const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty; S2 <= 8
-    const size_t lds = sizeof(float) * ((size_t)kv_div * chunk + 4 * kv_div * 64 + 8 * kv_div);
-    if (lds <= 64 * 1024 && (int64_t)B * S2 <= (int64_t)ws_rows * 8) {
-      const dim3 grid(H, A, S2);
-#define TTASR_MQ(NQ_) hipLaunchKernelGGL((cross_attn_mq_kernel<T, NQ_>), grid, dim3(256), lds, s, q, K, V, H, Tk, chunk, split_ws, sq)
-      switch (kv_div) {
+    const size_t lds = sizeof(float) * ((size_t)NQ * chunk + 4 * NQ * 64 + 8 * NQ);
+    const bool ws_ok = S2 == 1 || (int64_t)B * S2 <= (int64_t)ws_rows * 8;  // one slice: stored directly, no workspace
+    if (lds <= 64 * 1024 && ws_ok) {
+      const dim3 grid(H, A * groups, S2);
+#define TTASR_MQ(NQ_) \
+  hipLaunchKernelGGL((cross_attn_mq_kernel<T, NQ_>), grid, dim3(256), lds, s, q, K, V, H, Tk, chunk, split_ws, sq, kv_div, groups, nq_last, out)
+      switch (NQ) {
         case 2: TTASR_MQ(2); break; case 3: TTASR_MQ(3); break; case 4: TTASR_MQ(4); break; case 5: TTASR_MQ(5); break;
         case 6: TTASR_MQ(6); break; case 7: TTASR_MQ(7); break; default: TTASR_MQ(8); break;
       }
 #undef TTASR_MQ
-      hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
+      if (S2 > 1) hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
       return;
     }
   }
