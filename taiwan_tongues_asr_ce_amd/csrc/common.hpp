@@ -185,6 +185,9 @@ void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_f
 // encoder attention over fused qkv [B*T][3d] -> out [B*T][d]
 template <typename T> void launch_enc_attn_simple(const T* qkv, T* out, int B, int T_, int H, hipStream_t s);
 void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s);
+// cross-attention of n_q consecutive rows per clip against that clip's cross-KV cache, as one MFMA flash pass (prefill)
+void launch_cross_attn_flash_bf16(const bf16_t* q, const bf16_t* K, const bf16_t* V, bf16_t* out, int n_clips, int n_q, int H, int Tk,
+                                  hipStream_t s);
 
 // decoder
 // The rule scalars that change from one 30-s window to the next (prompt geometry with condition_on_previous_text, the token

@@ -748,6 +748,14 @@ template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
                               float* split_ws, SlabIn sq, int ws_rows) {
   if (ws_rows <= 0) ws_rows = B;  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
+  // many rows per clip (a long previous-text prompt in one prefill pass): the rows are the M dimension of an MFMA flash pass over
+  // the clip's frames (kernels_flash.hip, CROSS) - K and V are streamed once per (clip, head, 128 rows)
+  if constexpr (sizeof(T) == 2) {
+    if (split_ws && kv_div >= 32 && B % kv_div == 0 && sq.n == 0) {
+      launch_cross_attn_flash_bf16((const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, B / kv_div, kv_div, H, Tk, s);
+      return;
+    }
+  }
   // rows sharing a clip (beam hypotheses, prefill positions): one K/V stream per (clip, group of <= 8 rows) for all of them.
   // Measured at beam 5 (kernel + merge): 30 rows 18.9 us against 27.9 us for one workgroup per row (39.3 us when the rows do
   // not share); below 256 (row, head) items the frame-split per-row kernels fill the chip better (5 rows: 9.5 vs 11.8 us) and

@@ -30,8 +30,13 @@ __device__ __forceinline__ s16x4_t lds_tr16(const char* p) {
 
 constexpr int FA_QB = 128, FA_KB = 64;
 
+// CROSS = false: encoder self-attention, q / k / v rows interleaved in one [B][Tn][3d] tensor (n_k == Tn).
+// CROSS = true: the decoder's cross-attention for MANY query rows per clip (a prompt prefill pass): q = [clip][Tn][d] rows, K / V
+// from the cross-KV cache [clip][head][n_k][64] - the clip's frames are streamed once for all of its prompt positions.
+template <bool CROSS>
 __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
-                                                             int H) {
+                                                             int H, const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx,
+                                                             int n_k_cross) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K 8 KiB | V 8 KiB); reused for the O transpose
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hf = lane >> 5;
@@ -48,8 +53,12 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   }
   const int b = bh / H, h = bh - b * H, q0 = qb * FA_QB + wave * 32;
   const int d = H * 64;
-  const int64_t ld = 3 * (int64_t)d;
-  const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 64;
+  const int64_t ld = CROSS ? (int64_t)d : 3 * (int64_t)d;                      // query row stride
+  const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 64;                     // query rows of (b, h)
+  const int n_k = CROSS ? n_k_cross : Tn;                                       // keys
+  const int64_t kld = CROSS ? 64 : ld;                                          // key / value row stride
+  const bf16_t* kbase = CROSS ? kx + ((int64_t)b * H + h) * n_k * 64 : base + d;
+  const bf16_t* vbase = CROSS ? vx + ((int64_t)b * H + h) * n_k * 64 : base + 2 * d;
 
   // Q fragments (B operand of S^T): lane holds Q[q0 + r][16*ks + 8*hf .. +8]
   s16x8 qf[4];
@@ -64,9 +73,9 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   uint4 kreg0, kreg1, vreg0, vreg1;
 #define FA_G_LOAD(kt_)                                                      \
   do {                                                                      \
-    const int key_ = min((kt_) * FA_KB + srow, Tn - 1);                     \
-    const bf16_t* kp_ = base + (int64_t)key_ * ld + d + sc0 * 8;            \
-    const bf16_t* vp_ = base + (int64_t)key_ * ld + 2 * d + sc0 * 8;        \
+    const int key_ = min((kt_) * FA_KB + srow, n_k - 1);                    \
+    const bf16_t* kp_ = kbase + (int64_t)key_ * kld + sc0 * 8;              \
+    const bf16_t* vp_ = vbase + (int64_t)key_ * kld + sc0 * 8;              \
     kreg0 = *(const uint4*)kp_; kreg1 = *(const uint4*)(kp_ + 8);           \
     vreg0 = *(const uint4*)vp_; vreg1 = *(const uint4*)(vp_ + 8);           \
   } while (0)
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   float m_run = -1e30f, l_run = 0.f;
   constexpr float LOG2E = 1.4426950408889634f;
 
-  const int n_tiles = (Tn + FA_KB - 1) / FA_KB;
+  const int n_tiles = (n_k + FA_KB - 1) / FA_KB;
   FA_G_LOAD(0);
   FA_S_STORE(0);
   __syncthreads();
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           int key = kt * FA_KB + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hf;
-          if (key >= Tn) s[kb2][j] = -1e30f;
+          if (key >= n_k) s[kb2][j] = -1e30f;
         }
     }
     // ---- online softmax: this lane's query column ----
@@ -219,5 +228,12 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 
 void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s) {
   dim3 grid((T_ + FA_QB - 1) / FA_QB, H, B);
-  hipLaunchKernelGGL(enc_attn_flash_kernel, grid, dim3(256), 32768, s, qkv, out, T_, H);
+  hipLaunchKernelGGL(enc_attn_flash_kernel<false>, grid, dim3(256), 32768, s, qkv, out, T_, H, (const bf16_t*)nullptr,
+                     (const bf16_t*)nullptr, 0);
+}
+// q = [n_clips][n_q][d] (the n_q rows of a clip are consecutive), K / V = cross-KV cache of those clips, out like q
+void launch_cross_attn_flash_bf16(const bf16_t* q, const bf16_t* K, const bf16_t* V, bf16_t* out, int n_clips, int n_q, int H, int Tk,
+                                  hipStream_t s) {
+  dim3 grid((n_q + FA_QB - 1) / FA_QB, H, n_clips);
+  hipLaunchKernelGGL(enc_attn_flash_kernel<true>, grid, dim3(256), 32768, s, q, out, n_q, H, K, V, Tk);
 }

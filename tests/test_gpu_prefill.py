@@ -142,3 +142,37 @@ def test_prefill_bf16_consistent_with_token_by_token(setup):
         n = min(len(got.tokens[b]), len(want.tokens[b]))
         assert abs(score(got.tokens[b][:n], b) - score(want.tokens[b][:n], b)) < 0.5
     e.close(); e_ref.close()
+
+
+def test_prefill_cross_attention_kernels_agree(setup, monkeypatch):
+    """The prefill pass has three cross-attention kernels: one workgroup per (row, head) (TTASR_NO_XSPLIT), groups of <= 8 rows
+    per clip sharing one K/V stream (2 <= rows per clip < 32 in bf16, any count in f32), and - bf16, >= 32 rows per clip - the
+    MFMA flash pass with the rows as the M dimension.  A 70-token previous-text prompt (flash in bf16, groups in f32) and a
+    12-token one (groups) must give the same greedy tokens as the per-row kernel, with total log-probabilities within rounding."""
+    pd, dims, _, clips, _ = setup
+    rng = np.random.default_rng(11)
+    for compute, tol in ((COMPUTE_F32, 2e-3), (COMPUTE_BF16, 0.25)):
+        outs = {}
+        for per_row in (False, True):
+            if per_row:
+                monkeypatch.setenv("TTASR_NO_XSPLIT", "1")
+            else:
+                monkeypatch.delenv("TTASR_NO_XSPLIT", raising=False)
+            e = _engine(compute, 3)
+            st = e.special
+            e.log_mel(clips, want_output=False)
+            e.encode(3)
+            rng = np.random.default_rng(11)
+            for n_prev in (70, 12):
+                prompt = _prev_prompt(st, rng, n_prev)
+                outs[per_row, n_prev] = e.generate([prompt] * 3, e.gen_opts(6, True, no_speech=False))
+            e.close()
+        monkeypatch.delenv("TTASR_NO_XSPLIT", raising=False)
+        for n_prev in (70, 12):
+            a, b = outs[False, n_prev], outs[True, n_prev]
+            for r in range(3):
+                assert a.tokens[r][0] == b.tokens[r][0], (compute, n_prev, r)
+                if a.tokens[r] == b.tokens[r]:
+                    assert abs(float(a.sum_logprob[r]) - float(b.sum_logprob[r])) < tol, (compute, n_prev, r)
+            if compute == COMPUTE_F32:
+                assert a.tokens == b.tokens
