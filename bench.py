@@ -116,6 +116,39 @@ def cpu_baseline_full(dims, n_new: int):
                       f"4-token prompt + {n_new} greedy tokens, torch CPU f32, {cores} threads"}
 
 
+def cpu_baseline_matrix(n_new: int, budget_s: float = 40.0):
+    """SURVEY.md section 8(d)'s small rows: the CPU oracle end to end (log-mel -> encoder -> cross-KV -> 4-token prompt + n_new
+    greedy tokens, EOT suppressed) on the tiny and small geometries at B = 1 and B = 8, complete runs (no extrapolation).
+    Rows are taken in order of cost and the loop stops once `budget_s` of host time is spent (skipped rows are listed)."""
+    import torch
+    from oracle import whisper_ref as R
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import PRESETS, SpecialTokens
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    torch.set_grad_enabled(False)
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    rows, spent = [], 0.0
+    for name, B in (("tiny", 1), ("tiny", 8), ("small", 1), ("small", 8)):
+        if spent > budget_s:
+            rows.append({"model": name, "batch": B, "skipped": "host-time budget of the default run spent"})
+            continue
+        dims = PRESETS[name]
+        rd = R.Dims(**dims.as_dict())
+        W = R.to_torch(synth.state_dict(dims))
+        st = SpecialTokens.for_vocab(dims.vocab)
+        clips = [synth.noise_clip(b) for b in range(B)]
+        rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                        suppress=default_suppress(st, rd.vocab) + [st.eot], begin_suppress=[220, st.eot], timestamps=False)
+        t0 = time.perf_counter()
+        res = R.transcribe_tokens(clips, W, rd, [st.sot, st.lang_zh, st.transcribe, st.no_timestamps], rules, n_new)
+        dt = time.perf_counter() - t0
+        spent += dt
+        assert all(len(t) == n_new for t in res.tokens)
+        rows.append({"model": name, "batch": B, "seconds": round(dt, 2), "audio_s_per_s": round(B * 30.0 / dt, 2)})
+    return {"cores": cores, "kind": "port", "new_tokens": n_new, "rows": rows}
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -207,6 +240,9 @@ def main():
     ap.add_argument("--cpu-full", action="store_true",
                     help="run ONE full large-v3 B = 1 pass of the CPU oracle (minutes) and cache it as profiles/cpu_baseline_full.json")
     ap.add_argument("--write-crc", action="store_true", help="record the token checksum of this run as the expected one")
+    ap.add_argument("--clips", default="noise", choices=["noise", "tonal"],
+                    help="synthetic clip set of the timed steps (SURVEY.md 8d: 0.1 N(0,1) noise; the tonal set - five sines - is "
+                         "also measured as a side number by the default run)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -216,7 +252,7 @@ def main():
     import torch.distributed as dist
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, PRESETS
-    from taiwan_tongues_asr_ce_amd.dist import broadcast_weights, gather_tokens, init_process_group
+    from taiwan_tongues_asr_ce_amd.dist import barrier as dist_barrier, broadcast_weights, gather_tokens, init_process_group
     from taiwan_tongues_asr_ce_amd.engine import Engine
 
     rank, world, local = init_process_group()
@@ -224,6 +260,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % max(torch.cuda.device_count(), 1)   # ranks > devices only in the shared-GPU plumbing smoke test
     torch.cuda.set_device(local)
+    grp = dist.is_initialized()     # several ranks, or ONE rank with TTASR_DIST_FORCE=1 (the RCCL code paths on a 1-GPU box)
+    transport = dist.get_backend() if grp else None
     dims = PRESETS[args.model]
     B = args.batch
     C_ = max(1, args.contexts)
@@ -231,7 +269,7 @@ def main():
     eng = engines[0]
     t_load = time.perf_counter()
     for e_ in engines:
-        if world > 1 and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
+        if grp and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
             # north_star: rank 0 owns the checkpoint, the others receive it over RCCL (xGMI broadcast, 256 MB buckets)
             broadcast_weights(e_, dims, src_iter=synth.iter_weights(dims) if rank == 0 else None, device=local)
         else:
@@ -239,9 +277,10 @@ def main():
     t_load = time.perf_counter() - t_load
 
     # synthetic clips: rank r owns clips [r*B, (r+1)*B) of the global batch (weak scaling)
+    make_clip = synth.noise_clip if args.clips == "noise" else synth.tonal_clip
     pcm = torch.empty((B, 480000), dtype=torch.float32, device=f"cuda:{local}")
     for b in range(B):
-        pcm[b] = torch.from_numpy(synth.noise_clip(rank * B + b)).to(pcm.device)
+        pcm[b] = torch.from_numpy(make_clip(rank * B + b)).to(pcm.device)
     ns = [480000] * B
     torch.cuda.synchronize()    # the engine reads pcm on its own (non-blocking) stream
     st = eng.special
@@ -277,8 +316,8 @@ def main():
     for _ in range(args.warmup):
         step()
     phases, per_step = [], []
-    if world > 1:
-        dist.barrier()
+    if grp:
+        dist_barrier(local)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -287,17 +326,17 @@ def main():
         per_step.append(time.perf_counter() - ts)
         phases.append(eng.phase_ms())
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if grp:
+        dist_barrier(local)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grp:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert toks.shape == (world * B * C_, args.new_tokens)
 
     logits_spread = None
-    if args.validate or world > 1:
+    if args.validate or grp:
         from taiwan_tongues_asr_ce_amd.dist import gather_logits
         eng.log_mel([synth.noise_clip(0)], want_output=False)        # the SAME clip on every rank
         eng.encode(1)
@@ -377,8 +416,29 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "traffic_source": "profiles/xattn_pmc.json (static: separate rocprofv3 --pmc passes, not re-measured by this run)",
                 "avg_launch_us": round(k["ms"] * 1e3, 2), "bytes_per_launch": k["bytes"]}
-        # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time
-        # (a first untimed pass brings the clocks back up after the latency-bound decode phase)
+        # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time.
+        # (i) IN SITU: one extra untimed pass of the real encoder schedule with a hipEvent after
+        # every launch (option enc_kernel_timing, ttasr_encoder_kernel_ms) - each GEMM runs between its real neighbours, at the
+        # clock the sustained phase holds.  This is `mfma.frac`.
+        R_ = B * dims.n_audio_ctx
+        d_, f_, T_ = dims.d_model, dims.ffn_dim, dims.n_audio_ctx
+        cls_flops = {"qkv": 2.0 * R_ * 3 * d_ * d_ * dims.enc_layers, "out_proj": 2.0 * R_ * d_ * d_ * dims.enc_layers,
+                     "fc1": 2.0 * R_ * d_ * f_ * dims.enc_layers, "fc2": 2.0 * R_ * d_ * f_ * dims.enc_layers,
+                     "attention": 4.0 * B * T_ * T_ * d_ * dims.enc_layers,
+                     "conv": B * (2.0 * 2 * T_ * d_ * 3 * dims.n_mels + 2.0 * T_ * d_ * 3 * d_),
+                     "cross_kv": 2.0 * R_ * 2 * d_ * d_ * dims.dec_layers}
+        eng.set_option("enc_kernel_timing", 1)
+        eng.log_mel_device(pcm.data_ptr(), 480000, ns)
+        eng.encode(B)
+        eng.encode(B)                       # the second pass is the measured one (events already created)
+        km = eng.encoder_kernel_ms()
+        eng.set_option("enc_kernel_timing", 0)
+        gemm_cls = ("qkv", "out_proj", "fc1", "fc2")
+        insitu_tf = sum(cls_flops[k_] for k_ in gemm_cls) / (sum(km[k_] for k_ in gemm_cls) * 1e-3) / 1e12
+        insitu = {k_: {"ms": round(km[k_], 3), "tflops": round(cls_flops[k_] / (km[k_] * 1e-3) / 1e12, 1) if k_ in cls_flops and km[k_] > 0 else None}
+                  for k_ in km}
+        # (ii) isolated relaunch loops of the same four kernels (round-2 figure, kept for comparison: 30 back-to-back launches
+        # of ONE kernel right after a clock-recovery pass read higher than the sustained phase)
         names = ("enc_gemm_qkv", "enc_gemm_out", "enc_gemm_fc1", "enc_gemm_fc2")
         for n in names:
             eng.bench_kernel(n, B, iters=10)
@@ -400,6 +460,20 @@ def main():
         except Exception:
             pass
         ph = {kk: round(float(np.mean([p[kk] for p in phases])), 2) for kk in phases[0]}
+        # phase-level fractions.  Decode: SURVEY.md 8(d)'s algorithmic bytes per step at the mean
+        # position - decoder weights (every decoder-layer matrix + the tied embedding, read once per step for the whole batch)
+        # + the cross-KV of every row + the self-KV read so far + the logits written - over the measured time per step.
+        n_steps = len(prompt) + args.new_tokens - 1
+        t_mean = (n_steps - 1) / 2.0
+        dec_w = dims.dec_layers * (8 * d_ * d_ + 2 * d_ * f_) + dims.vocab * d_
+        step_bytes = (dec_w * esz + B * dims.dec_layers * 2 * T_ * d_ * esz + B * dims.dec_layers * 2 * d_ * esz * t_mean
+                      + B * dims.vocab * 4)
+        ms_step = ph["decode"] / n_steps
+        roof["decode_phase"] = {"bytes_per_step": round(step_bytes), "steps": n_steps, "ms_per_step": round(ms_step, 4),
+                                "achieved_GBps": round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+                                "frac_of_8TBps": round(step_bytes / (ms_step * 1e-3) / 8e12, 4),
+                                "floor_ms_at_8TBps": round(step_bytes / 8e12 * 1e3, 4)}
+        enc_phase_flops = sum(v for k_, v in cls_flops.items() if k_ != "cross_kv")
         out = {
             "metric": "audio-sec/s (RTF) whisper-large-v3 greedy, 30 s clips, batch 32; 1/2/4/8 GPU",
             "value": round(world * C_ * B * 30.0 * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world,
@@ -410,16 +484,36 @@ def main():
                                    f"clips per GPU resident in HBM, log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
                        "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens,
+                       "transport": transport,
                        "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else "") +
                                       (" (ranks share GPUs over gloo: plumbing check, not a scaling number)"
                                        if world > torch.cuda.device_count() else ""),
                        "rank_logits_spread": logits_spread, "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
-            "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted)", "achieved_tflops": round(enc_tf, 1), "peak_tflops": 2500.0,
-                     "frac": round(enc_tf / 2500.0, 4), "pmc_mfma_busy_frac": pmc_busy,
-                     "pmc_source": "profiles/r2_pmc.json (static)"},
+            "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted), timed IN SITU: one pass of the real "
+                               "encoder schedule with a hipEvent after every launch", "achieved_tflops": round(insitu_tf, 1),
+                     "peak_tflops": 2500.0, "frac": round(insitu_tf / 2500.0, 4),
+                     "in_situ_by_class": insitu,
+                     "encoder_phase_frac": round(enc_phase_flops / (ph["encoder"] * 1e-3) / 2.5e15, 4),
+                     "cross_kv_phase_frac": round(cls_flops["cross_kv"] / (ph["cross_kv"] * 1e-3) / 2.5e15, 4),
+                     "isolated_relaunch_tflops": round(enc_tf, 1), "isolated_relaunch_frac": round(enc_tf / 2500.0, 4),
+                     "pmc_mfma_busy_frac": pmc_busy, "pmc_source": "profiles/r2_pmc.json (static)"},
         }
+        if world == 1 and C_ == 1 and args.clips == "noise":
+            # SURVEY.md 8(d)'s tonal variant (five sines: exercises the per-clip max - 8 clamp of the log-mel): the same step on
+            # the other clip set, a side number (the weights are random, so the content changes the front end, not the decode)
+            for b in range(B):
+                pcm[b] = torch.from_numpy(synth.tonal_clip(rank * B + b)).to(pcm.device)
+            torch.cuda.synchronize()
+            one_pass(eng)
+            tt = []
+            for _ in range(3):
+                ts = time.perf_counter()
+                one_pass(eng)
+                tt.append(time.perf_counter() - ts)
+            out["config"]["tonal_clips"] = {"ms_per_step": round(float(np.median(tt)) * 1e3, 2),
+                                            "audio_s_per_s": round(B * 30.0 / float(np.median(tt)), 1), "steps": 3}
         if check is not None:
             out["output_check"] = check
         if world == 1 and not args.no_cpu_baseline:
@@ -434,6 +528,8 @@ def main():
                     out["cpu_baseline"]["full_run_cached"] = json.load(f)
             except Exception:
                 pass
+            if args.model == "large-v3":   # the tiny / small rows of SURVEY.md 8(d), complete runs, bounded host time
+                out["cpu_baseline"]["matrix"] = cpu_baseline_matrix(args.new_tokens)
         if world == 1 and C_ == 1 and args.more_in_flight:
             # Side measurement, NOT `value`: the same step with a second independent context passing its own batch of
             # B clips concurrently (2 x B clips in flight).  One context's latency-bound decode chain leaves most of the
@@ -462,8 +558,8 @@ def main():
         print(json.dumps(out), flush=True)
     for e_ in engines:
         e_.close()
-    if world > 1:
-        dist.barrier()
+    if grp:
+        dist_barrier(local)
         dist.destroy_process_group()
 
 

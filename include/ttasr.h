@@ -196,10 +196,28 @@ int ttasr_align(ttasr_ctx* ctx, int32_t clip, const int32_t* tokens_host, int32_
  * (no context): CTranslate2 does this step in C++ too. */
 int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_row, int32_t* out_col, int32_t* out_len);
 
+/* ---- kernel-selection overrides (tests, A/B measurements) ----------------------------------------- */
+/* The release library reads NO environment variable; every deviation from the measured configuration is an explicit call.
+ * Keys (value 0 / 1 unless stated; defaults in brackets): "flash" [1] MFMA flash attention in the encoder (0: the
+ * one-query-per-wave f32 kernel); "prefill" [1] batched prompt prefill (0: prompts token by token); "xsplit" [1] frame-split
+ * cross-attention for small batches; "graph" [1] hipGraph replay of the decode step; "generic_kernels" [0] the 64x64 generic
+ * GEMM / per-row kernels everywhere; "prefill_tiled" [0]; "prefill_ns_min" [16] (tokens); "enc_residual_epilogue" [0];
+ * "enc_gemm" [0] = 1 | 2 | 3 forces one encoder GEMM kernel; "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =
+ * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "weights_nontemporal" [1] (these two are process-wide);
+ * "enc_kernel_timing" [0] per-launch events in ttasr_encode (see ttasr_encoder_kernel_ms).
+ * Drops the captured decode graphs.  Unknown key or value out of range: TTASR_E_INVALID. */
+int ttasr_set_option(ttasr_ctx* ctx, const char* key, int32_t value);
+
 /* ---- measurement --------------------------------------------------------------------------------- */
 /* hipEvent times (ms) of the last log_mel / encode (stem+layers, cross-KV) / generate calls:
  * out[0]=mel out[1]=encoder out[2]=cross_kv out[3]=decode. */
 int ttasr_phase_ms(ttasr_ctx* ctx, float out_ms[4]);
+/* Where the encoder phase went, IN SITU: with option "enc_kernel_timing" = 1 the next ttasr_encode records one hipEvent after
+ * every launch of its schedule (not an isolated relaunch loop: each kernel runs between its real neighbours) and this call
+ * returns the per-class sums of that pass in ms: out[0] conv stem, [1] LayerNorms, [2] qkv GEMMs, [3] attention, [4] out-proj
+ * GEMMs, [5] fc1 GEMMs, [6] fc2 GEMMs, [7] cross-KV GEMMs.  The extra events cost a few microseconds per launch; keep the
+ * option off in timed runs. */
+int ttasr_encoder_kernel_ms(ttasr_ctx* ctx, float out_ms[8]);
 /* Re-launches one named hot kernel `iters` times on the context's stream with the state left by the
  * last encode/generate (B clips) and returns its average duration measured with hipEvents, plus the
  * algorithmic bytes and flops one launch moves/does.  Names: "xattn" (decoder cross-attention),

@@ -15,7 +15,7 @@ SYMBOLS = [
     "ttasr_create", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
     "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_log_mel_windows", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
     "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
-    "ttasr_phase_ms", "ttasr_bench_kernel", "ttasr_sync",
+    "ttasr_set_option", "ttasr_phase_ms", "ttasr_encoder_kernel_ms", "ttasr_bench_kernel", "ttasr_sync",
 ]
 
 
@@ -82,7 +82,9 @@ def load() -> C.CDLL:
     lib.ttasr_apply_rules.argtypes = [vp, vp, i32p, i32, i32, C.POINTER(GenOpts), vp, i32p]
     lib.ttasr_align.argtypes = [vp, i32, i32p, i32, i32p, i32, f32p, f32p]
     lib.ttasr_dtw.argtypes = [f32p, i32, i32, i32p, i32p, i32p]
+    lib.ttasr_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ttasr_phase_ms.argtypes = [vp, f32p]
+    lib.ttasr_encoder_kernel_ms.argtypes = [vp, f32p]
     lib.ttasr_bench_kernel.argtypes = [vp, C.c_char_p, i32, i32, f32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ttasr_sync.argtypes = [vp]
     for s in SYMBOLS:

@@ -17,6 +17,14 @@ class ASRInterface:
     async def transcribe(self, client):
         raise NotImplementedError("This method should be implemented by subclasses.")
 
+    def _vad_is_active(self) -> bool:
+        """True when vad_filter=True really filters: the operator supplied a speech-probability source on the model, or the
+        default kwargs opt into the energy stand-in."""
+        if getattr(self.asr_pipeline, "vad_speech_prob_fn", None) is not None:
+            return True
+        params = self.default_transcribe_kwargs.get("vad_parameters") or {}
+        return params.get("backend") == "energy"
+
     def warm_up(self):
         raise NotImplementedError("This method should be implemented by subclasses.")
 
@@ -58,6 +66,18 @@ class MI355XWhisperASR(ASRInterface):
                 warnings.filterwarnings("ignore", message="vad_filter=True")
                 segments, info = self.asr_pipeline.transcribe(audio, **kw)
                 segments = list(segments)
+                if len(segments) == 0 and kw.get("vad_filter") and self._vad_is_active():
+                    # faster_whisper_asr.py:186-196: nothing came back with VAD on -> once more with VAD off, so that an
+                    # over-eager filter cannot swallow a whole utterance.  (The reference re-reads a temp file it has
+                    # already deleted at :179 and so always falls into its `except: pass`; here the audio is still in hand.)
+                    # Only when a VAD source is configured: without one vad_filter=True already kept the whole clip.
+                    try:
+                        retry = dict(kw, vad_filter=False)
+                        segments, info = self.asr_pipeline.transcribe(audio, **retry)
+                        segments = list(segments)
+                    except Exception as e:      # the reference swallows a failing retry too (:197-198)
+                        logger.debug("retry without VAD failed: %s", e)
+                        segments = []
             if len(segments) == 0:
                 return None
             text = " ".join(getattr(s, "text", "").strip() for s in segments)
@@ -77,6 +97,14 @@ class MI355XWhisperASR(ASRInterface):
         except Exception as e:  # the reference logs and returns None (faster_whisper_asr.py:260-267)
             logger.error("transcribe failed: %s", e)
             return None
+
+    def _vad_is_active(self) -> bool:
+        """True when vad_filter=True really filters: the operator supplied a speech-probability source on the model, or the
+        default kwargs opt into the energy stand-in."""
+        if getattr(self.asr_pipeline, "vad_speech_prob_fn", None) is not None:
+            return True
+        params = self.default_transcribe_kwargs.get("vad_parameters") or {}
+        return params.get("backend") == "energy"
 
     def warm_up(self):
         wav = os.environ.get("TTASR_WARMUP_WAV")

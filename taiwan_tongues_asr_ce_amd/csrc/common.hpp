@@ -241,8 +241,8 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
                               SlabIn sq = SlabIn{} /*q from K-split partial tiles*/,
                               int ws_rows = 0 /*rows the workspace was sized for (0: B); rows that share a clip (kv_div 2..8)
                                                 are served by one K/V stream per clip when they fit*/);
-extern int g_skinny_nt;     // TTASR_W_NT: nontemporal weight loads in the decode GEMMs (A/B experiments)
-extern int g_xattn_variant;  // TTASR_XATTN: cross-attention kernel variant (A/B experiments)
+extern int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs (A/B experiments)
+extern int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant (A/B experiments)
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
 // per-row history state uploaded by the host)
 struct BeamRowState { const int32_t *n_sampled, *last_tok, *pen_tok, *last_ts; const uint8_t* mask; };

@@ -57,6 +57,7 @@ struct ttasr_ctx {
   int pages_per_seq = 0;
   std::vector<void*> allocs;
   struct Pool { char* base = nullptr; size_t cap = 0, used = 0; } small_pool, big_pool;  // bump arenas (see dalloc)
+  size_t arena_hint = 0;   // rough device footprint of this context (bytes): picks the big-arena chunk size
   std::unordered_map<std::string, Slot> slots;
 
   // weights
@@ -91,11 +92,11 @@ struct ttasr_ctx {
   static constexpr int skip_mask = 0;  // release builds cannot drop work from the decode step
 #endif
   float* slab = nullptr;      // [16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
-  int ks_want[4] = {0, 0, 0, 0};  // TTASR_KS=d,q,qkv,fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
-  int gemm_force = 0;         // TTASR_GEMM=v1|v2|v3 (A/B testing of the encoder GEMM kernels)
-  bool no_flash = false;      // TTASR_NO_FLASH
-  int prefill_ns_min = 16;    // TTASR_PREFILL_NS_MIN: shortest prompt whose sot position is taken from the prefill pass
-  bool enc_res_epilogue = false;  // TTASR_ENC_RES_EPI: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
+  int ks_want[4] = {0, 0, 0, 0};  // option ksplit_out / _q / _qkv / _fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
+  int gemm_force = 0;         // option enc_gemm = 1|2|3 (A/B testing of the encoder GEMM kernels)
+  bool no_flash = false;      // option flash = 0
+  int prefill_ns_min = 16;    // option prefill_ns_min: shortest prompt whose sot position is taken from the prefill pass
+  bool enc_res_epilogue = false;  // option enc_residual_epilogue: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
@@ -103,11 +104,17 @@ struct ttasr_ctx {
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
-  bool no_xsplit = false;   // TTASR_NO_XSPLIT: never split the cross-attention frames over workgroups (A/B testing)
-  bool no_prefill = false;  // TTASR_NO_PREFILL: feed prompts token by token (A/B testing)
-  bool prefill_tiled = false;  // TTASR_PREFILL_TILED: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
+  bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)
+  bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)
+  bool prefill_tiled = false;  // option prefill_tiled: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
   hipEvent_t ev[8]{};
   float phase_ms[4]{0, 0, 0, 0};
+  // option enc_kernel_timing: one hipEvent after every launch of run_encoder / run_cross_kv, so the NEXT ttasr_encode also
+  // reports where the phase went, in situ (class sums: ttasr_encoder_kernel_ms).  Off in the timed benchmark steps.
+  bool enc_timing = false;
+  std::vector<hipEvent_t> enc_ev;
+  std::vector<int> enc_ev_class;
+  float enc_class_ms[8]{0, 0, 0, 0, 0, 0, 0, 0};
 
   // decode-step graphs keyed by (B, with_logits)
   struct GraphKey { int B; int mode; int variant; hipGraphExec_t exec; };
@@ -145,14 +152,26 @@ int dalloc(ttasr_ctx* c, P** p, size_t bytes, bool zero = true) {
   if (bytes == 0) bytes = 16;
   bytes = (bytes + 255) & ~(size_t)255;
   ttasr_ctx::Pool& pool = bytes < (1u << 20) ? c->small_pool : c->big_pool;
-  if (pool.used + bytes > pool.cap) {
-    const size_t chunk = &pool == &c->small_pool ? (size_t)64 << 20 : (size_t)1 << 30;
-    const size_t cap = bytes > chunk ? bytes : chunk;
+  // big chunks: 1 GiB for real models; small geometries (tests, streaming-size engines) open 64 MiB chunks instead of pinning a
+  // gigabyte each - the hint is the footprint ttasr_create estimated for this context
+  const size_t big_chunk = c->arena_hint >= ((size_t)1 << 30) ? (size_t)1 << 30 : (size_t)64 << 20;
+  const size_t chunk = &pool == &c->small_pool ? (size_t)64 << 20 : big_chunk;
+  if (bytes > chunk / 2) {
+    // an oversize request gets its own allocation and leaves the active chunk (and its unused tail) in service
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, cap);
-    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     c->allocs.push_back(q);
-    pool.base = (char*)q; pool.cap = cap; pool.used = 0;
+    if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
+    *p = (P*)q;
+    return 0;
+  }
+  if (pool.used + bytes > pool.cap) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, chunk);
+    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", chunk, hipGetErrorString(e));
+    c->allocs.push_back(q);
+    pool.base = (char*)q; pool.cap = chunk; pool.used = 0;
   }
   void* q = pool.base + pool.used;
   pool.used += bytes;
@@ -288,8 +307,8 @@ int build_weights(ttasr_ctx* c) {
       TRY(packed(p + ".fc2.weight", &L.w2_sh, d, F, 0));
     }
   }
-  c->stage_elems = std::max<size_t>((size_t)V * d, (size_t)d * 3 * d);
-  c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)F * d);
+  c->stage_elems = 0;   // every host upload is staged in the source layout: the largest registered tensor decides
+  for (auto& kv : c->slots) c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)(kv.second.rows * kv.second.cols));
   TRY(dalloc(c, &c->stage_f32, c->stage_elems * 4, false));
   TRY(dalloc(c, &c->stage_raw, c->stage_elems * 4, false));
   return 0;
@@ -369,7 +388,7 @@ template <typename T>
 void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
-      const int v = c->gemm_force;  // TTASR_GEMM: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage
+      const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage
       // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
       const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
@@ -397,6 +416,16 @@ GemmArgs lin_args(const void* A, const void* W, int M, int N, int K) {
   return g;
 }
 
+// in-situ kernel classes of the encoder phase (ttasr_encoder_kernel_ms)
+enum EncClass { EC_CONV = 0, EC_LN = 1, EC_QKV = 2, EC_ATTN = 3, EC_OUT = 4, EC_FC1 = 5, EC_FC2 = 6, EC_XKV = 7 };
+void enc_mark(ttasr_ctx* c, int cls) {   // cls < 0: the start mark
+  if (!c->enc_timing) return;
+  const size_t i = c->enc_ev_class.size();
+  if (i >= c->enc_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->enc_ev.push_back(e); }
+  hipEventRecord(c->enc_ev[i], c->cur);
+  c->enc_ev_class.push_back(cls);
+}
+
 template <typename T>
 int run_cross_kv(ttasr_ctx* c, int B) {
   const int d = c->d, T_ = c->T;
@@ -406,6 +435,7 @@ int run_cross_kv(ttasr_ctx* c, int B) {
     g.epi.out_t = (char*)c->xkv + (size_t)l * c->xkv_layer_elems * c->esz;
     g.epi.headsplit = 1; g.epi.hs_T = T_; g.epi.hs_H = c->H; g.epi.hs_d = d; g.epi.hs_which = c->xkv_which_elems;
     gemm<T>(c, g);
+    enc_mark(c, EC_XKV);
   }
   return 0;
 }
@@ -415,6 +445,8 @@ int run_encoder(ttasr_ctx* c, int B) {
   const int d = c->d, T_ = c->T, F = c->F, M = c->M, ffn = c->ffn;
   hipStream_t s = c->cur;
   hipEventRecord(c->ev[2], s);
+  c->enc_ev_class.clear();
+  enc_mark(c, -1);
   {  // conv1 as GEMM over the zero-padded time-major mel image: row t of A = rows t..t+2 of the image
     GemmArgs g; g.A = c->mel_t; g.W = c->conv1_w; g.M = F; g.N = d; g.K = 3 * M; g.lda = M; g.ldw = 3 * M;
     g.batch = B; g.batch_stride_a = (int64_t)(F + 2) * M;
@@ -428,6 +460,7 @@ int run_encoder(ttasr_ctx* c, int B) {
     g.epi.bias = c->conv2_b; g.epi.act = 1; g.epi.rowtab = c->epos; g.epi.rowmod = T_; g.epi.out_f32 = c->x;
     g.epi.ldc = d; g.epi.batch_stride_c = (int64_t)T_ * d;
     gemm<T>(c, g);
+    enc_mark(c, EC_CONV);
   }
   const int R = B * T_;
   // bf16 mode: the out-proj / fc2 GEMMs write their result (bias added) as a T "delta" into the h buffer (dead at that
@@ -441,25 +474,30 @@ int run_encoder(ttasr_ctx* c, int B) {
     if (pending) launch_layernorm_add<T>(c->x, (const T*)c->h, g_, b_, (T*)out, R, d, s);
     else launch_layernorm<T>(c->x, g_, b_, (T*)out, R, d, s);
     pending = false;
+    enc_mark(c, EC_LN);
   };
-  auto residual_gemm = [&](const void* A, const void* W, const float* bias, int K) {
+  auto residual_gemm = [&](const void* A, const void* W, const float* bias, int K, int cls) {
     GemmArgs g = lin_args<T>(A, W, R, d, K); g.epi.bias = bias;
     if (delta) { g.epi.out_t = c->h; pending = true; }
     else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
     gemm<T>(c, g);
+    enc_mark(c, cls);
   };
   for (int l = 0; l < c->cfg.enc_layers; ++l) {
     const EncLayerW& L = c->enc[l];
     ln(L.ln1g, L.ln1b, c->h);
     { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
+    enc_mark(c, EC_QKV);
     if (sizeof(T) == 2 && !c->force_basic && !c->no_flash)
       launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
     else
       launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
-    residual_gemm(c->att, L.wo, L.bo, d);
+    enc_mark(c, EC_ATTN);
+    residual_gemm(c->att, L.wo, L.bo, d, EC_OUT);
     ln(L.ln2g, L.ln2b, c->h);
     { GemmArgs g = lin_args<T>(c->h, L.w1, R, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->mid; gemm<T>(c, g); }
-    residual_gemm(c->mid, L.w2, L.b2, ffn);
+    enc_mark(c, EC_FC1);
+    residual_gemm(c->mid, L.w2, L.b2, ffn, EC_FC2);
   }
   ln(c->elnf_g, c->elnf_b, c->enc_out);
   hipEventRecord(c->ev[3], s);
@@ -661,7 +699,7 @@ int prefill_no_speech(ttasr_ctx* c, int n_seq, int npos, int sot, int no_speech_
 }
 
 // One decode step = one dependent chain of ~355 launches on the context's stream, captured as a hipGraph.  Splitting the
-// batch into two half-batch chains on two streams inside the graph (round 1's TTASR_DUAL experiment: +4 % then) doubles the
+// batch into two half-batch chains on two streams inside the graph (round 1's dual-chain experiment: +4 % then) doubles the
 // launch count and, with the round-2 kernels, measures 3 % SLOWER (3.15 vs 3.05 ms per step): removed.
 template <typename T>
 void run_decode_step(ttasr_ctx* c, int B, int mode) {
@@ -754,6 +792,31 @@ void drop_rule_graphs(ttasr_ctx* c) {
   c->graphs.resize(k);
 }
 
+// Kernel-selection overrides (ttasr_set_option).  Everything defaults to the measured configuration; an override changes
+// which kernels the captured decode graphs hold, so the graphs are dropped.
+int set_option(ttasr_ctx* c, const std::string& key, int v) {
+  const bool on = v != 0;
+  if (key == "enc_kernel_timing") { c->enc_timing = on; return 0; }   // measurement only: the captured decode graphs stay
+  if (key == "flash") c->no_flash = !on;
+  else if (key == "prefill") c->no_prefill = !on;
+  else if (key == "xsplit") c->no_xsplit = !on;
+  else if (key == "graph") c->use_graph = on;
+  else if (key == "generic_kernels") c->force_basic = on;
+  else if (key == "prefill_tiled") c->prefill_tiled = on;
+  else if (key == "prefill_ns_min") { if (v < 0) return 1; c->prefill_ns_min = v; }
+  else if (key == "enc_residual_epilogue") c->enc_res_epilogue = on;
+  else if (key == "enc_gemm") { if (v < 0 || v > 3) return 1; c->gemm_force = v; }
+  else if (key == "ksplit_out") { if (v < 0 || v > 16) return 1; c->ks_want[0] = v; }
+  else if (key == "ksplit_q") { if (v < 0 || v > 16) return 1; c->ks_want[1] = v; }
+  else if (key == "ksplit_qkv") { if (v < 0 || v > 16) return 1; c->ks_want[2] = v; }
+  else if (key == "ksplit_fc2") { if (v < 0 || v > 16) return 1; c->ks_want[3] = v; }
+  else if (key == "xattn_nontemporal") g_xattn_variant = on ? 1 : 0;   // process-wide (kernel template choice)
+  else if (key == "weights_nontemporal") g_skinny_nt = on ? 1 : 0;     // process-wide
+  else return 1;
+  drop_graphs(c);
+  return 0;
+}
+
 int reset_search(ttasr_ctx* c, int B) {
   hipStream_t s = c->stream;
   HIPCHK(c, hipMemsetAsync(c->st.step, 0, 16, s));
@@ -814,7 +877,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
       cfg->n_text_ctx < 2 || cfg->n_text_ctx > 448 || cfg->enc_layers < 1 || cfg->dec_layers < 1 || cfg->max_batch < 1)
     return fail(nullptr, TTASR_E_INVALID, "unsupported geometry");
   if (cfg->compute_type != TTASR_COMPUTE_F32 && cfg->compute_type != TTASR_COMPUTE_BF16)
-    return fail(nullptr, TTASR_E_INVALID, "compute_type must be TTASR_COMPUTE_F32 or TTASR_COMPUTE_BF16");
+    return fail(nullptr, TTASR_E_INVALID, "compute_type must be 0 (f32) or 1 (bf16)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -826,33 +889,57 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   c->T = cfg->n_audio_ctx; c->F = 2 * c->T; c->d = cfg->d_model; c->H = cfg->n_heads; c->ffn = cfg->ffn_dim;
   c->V = cfg->vocab; c->ldv = (cfg->vocab + 63) / 64 * 64; c->M = cfg->n_mels; c->maxB = cfg->max_batch;
   c->n_samples = c->F * 160;
-  c->force_basic = getenv("TTASR_FORCE_BASIC") != nullptr;
-  c->use_graph = getenv("TTASR_NO_GRAPH") == nullptr;
-  c->no_prefill = getenv("TTASR_NO_PREFILL") != nullptr;
-  c->prefill_tiled = getenv("TTASR_PREFILL_TILED") != nullptr;
-  c->no_xsplit = getenv("TTASR_NO_XSPLIT") != nullptr;
-#ifdef TTASR_EXPERIMENTS
-  if (getenv("TTASR_SKIP")) c->skip_mask = atoi(getenv("TTASR_SKIP"));
-#endif
-  if (const char* v = getenv("TTASR_KS")) sscanf(v, "%d,%d,%d,%d", &c->ks_want[0], &c->ks_want[1], &c->ks_want[2], &c->ks_want[3]);
-  c->no_flash = getenv("TTASR_NO_FLASH") != nullptr;
-  if (const char* v = getenv("TTASR_PREFILL_NS_MIN")) c->prefill_ns_min = atoi(v);
-  c->enc_res_epilogue = getenv("TTASR_ENC_RES_EPI") != nullptr;
-  if (const char* v = getenv("TTASR_GEMM")) c->gemm_force = (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0;
-  if (const char* v = getenv("TTASR_XATTN")) g_xattn_variant = atoi(v);
-  // nontemporal weight loads: the 1.8 GB of decoder weights a step streams can never stay cached (measured -1 % per step)
-  g_skinny_nt = getenv("TTASR_W_NT") ? atoi(getenv("TTASR_W_NT")) : 1;
+  // The release library reads NO environment variable: every kernel-selection override goes through ttasr_set_option (an
+  // explicit call a test or a measurement script makes).  Experiment builds (-DTTASR_EXPERIMENTS) additionally map the old
+  // TTASR_* variables onto the same options, after the context exists (below).
   ttasr_ctx* p = c.get();
   auto die = [&](int rc) { g_create_error = p->err; ttasr_destroy(c.release()); return rc; };
   if (hipSetDevice(device_id) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipSetDevice(%d) failed", device_id));
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
   p->cur = p->stream;
+  {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
+    const size_t d = p->d, ffn = p->ffn, T = p->T, B = p->maxB;
+    const size_t w = ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);
+    const size_t act = B * T * (4 * d + 3 * d + ffn + 2 * d) + (size_t)cfg->dec_layers * 2 * B * T * d + (size_t)cfg->dec_layers * 2 * B * cfg->n_text_ctx * d;
+    p->arena_hint = (w + act) * p->esz;
+  }
   int rc = build_weights(p);
   if (rc) return die(rc);
   rc = build_workspaces(p);
   if (rc) return die(rc);
+#ifdef TTASR_EXPERIMENTS
+  {  // experiment builds only: the environment switches of the lab notebook (tools/microbench/README.md)
+    static const struct { const char* env; const char* key; int on; } flags[] = {
+        {"TTASR_FORCE_BASIC", "generic_kernels", 1}, {"TTASR_NO_GRAPH", "graph", 0},          {"TTASR_NO_PREFILL", "prefill", 0},
+        {"TTASR_PREFILL_TILED", "prefill_tiled", 1}, {"TTASR_NO_XSPLIT", "xsplit", 0},        {"TTASR_NO_FLASH", "flash", 0},
+        {"TTASR_ENC_RES_EPI", "enc_residual_epilogue", 1}};
+    for (auto& f : flags) if (getenv(f.env)) set_option(p, f.key, f.on);
+    if (getenv("TTASR_SKIP")) p->skip_mask = atoi(getenv("TTASR_SKIP"));
+    if (const char* v = getenv("TTASR_KS")) {
+      int ks[4] = {0, 0, 0, 0};
+      sscanf(v, "%d,%d,%d,%d", &ks[0], &ks[1], &ks[2], &ks[3]);
+      set_option(p, "ksplit_out", ks[0]); set_option(p, "ksplit_q", ks[1]); set_option(p, "ksplit_qkv", ks[2]); set_option(p, "ksplit_fc2", ks[3]);
+    }
+    if (const char* v = getenv("TTASR_PREFILL_NS_MIN")) set_option(p, "prefill_ns_min", atoi(v));
+    if (const char* v = getenv("TTASR_GEMM")) set_option(p, "enc_gemm", (v[0] == 'v' && v[1] >= '1' && v[1] <= '3') ? v[1] - '0' : 0);
+    if (const char* v = getenv("TTASR_XATTN")) set_option(p, "xattn_nontemporal", atoi(v) & 1);
+    if (const char* v = getenv("TTASR_W_NT")) set_option(p, "weights_nontemporal", atoi(v));
+  }
+#endif
   *out_ctx = c.release();
+  return TTASR_OK;
+  });
+}
+
+int ttasr_set_option(ttasr_ctx* c, const char* key, int32_t value) {
+  return guarded(c, [&]() -> int {
+  if (!c) return TTASR_E_INVALID;
+  if (!key) return fail(c, TTASR_E_INVALID, "key is NULL");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = set_option(c, key, value);
+  if (rc) return fail(c, TTASR_E_INVALID, "unknown option '%s' (or value %d out of range)", key, value);
   return TTASR_OK;
   });
 }
@@ -863,6 +950,7 @@ void ttasr_destroy(ttasr_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   drop_graphs(c);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  for (auto& e : c->enc_ev) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -917,7 +1005,7 @@ int ttasr_load_tensor_device(ttasr_ctx* c, const char* name, const void* data_de
   return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (!name || !data_dev || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
-  if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16) return fail(c, TTASR_E_INVALID, "dtype must be TTASR_DTYPE_F32 or TTASR_DTYPE_BF16");
+  if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16) return fail(c, TTASR_E_INVALID, "dtype must be 0 (float32) or 1 (bfloat16 bits)");
   HIPCHK(c, hipSetDevice(c->device));
   return ingest_tensor(c, name, data_dev, dtype == TTASR_DTYPE_BF16, dims, ndim);
   });
@@ -1051,7 +1139,24 @@ int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
   HIPCHK(c, hipGetLastError());
   hipEventElapsedTime(&c->phase_ms[1], c->ev[2], c->ev[3]);
   hipEventElapsedTime(&c->phase_ms[2], c->ev[3], c->ev[4]);
+  if (c->enc_timing) {
+    for (float& v : c->enc_class_ms) v = 0.f;
+    for (size_t i = 1; i < c->enc_ev_class.size(); ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, c->enc_ev[i - 1], c->enc_ev[i]);
+      if (c->enc_ev_class[i] >= 0 && c->enc_ev_class[i] < 8) c->enc_class_ms[c->enc_ev_class[i]] += ms;
+    }
+  }
   c->B_enc = B;
+  return TTASR_OK;
+  });
+}
+
+int ttasr_encoder_kernel_ms(ttasr_ctx* c, float out[8]) {
+  return guarded(c, [&]() -> int {
+  if (!c || !out) return TTASR_E_INVALID;
+  if (!c->enc_timing) return fail(c, TTASR_E_INVALID, "set option enc_kernel_timing = 1 and run ttasr_encode first");
+  for (int i = 0; i < 8; ++i) out[i] = c->enc_class_ms[i];
   return TTASR_OK;
   });
 }
@@ -1650,7 +1755,11 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
   auto once = [&](void) -> int {
     if (k == "xattn") {
       static int layer_rr = 0;  // walk the layers: one layer's K/V (246 MB at B=32) would sit in the Infinity Cache
+#ifdef TTASR_EXPERIMENTS
       static const bool same_layer = getenv("TTASR_BENCH_XATTN_SAME_LAYER") != nullptr;  // (that case, for comparison)
+#else
+      constexpr bool same_layer = false;
+#endif
       const char* Kx = (const char*)c->xkv + (size_t)(same_layer ? 0 : layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
       if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
                                                     (bf16_t*)c->datt, B, c->H, c->T, 1, s);

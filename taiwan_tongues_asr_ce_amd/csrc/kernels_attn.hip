@@ -147,7 +147,7 @@ template <> __device__ __forceinline__ void store_row<bf16_t>(bf16_t* p, const f
 // over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
-int g_xattn_variant = 1;  // TTASR_XATTN (experiments); default 1 = nontemporal K/V loads
+int g_xattn_variant = 1;  // option xattn_nontemporal; default 1 = nontemporal K/V loads
 using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 
 // Single pass, one memory round trip for pos <= 32*UNROLL cached keys: every lane keeps an online-softmax
@@ -790,7 +790,7 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
     hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
     return;
   }
-  // g_xattn_variant (TTASR_XATTN, A/B testing): 1 = nontemporal K/V loads (default), 0 = plain.  (16 rows in flight per lane and
+  // g_xattn_variant (option xattn_nontemporal, A/B testing): 1 = nontemporal K/V loads (default), 0 = plain.  (16 rows in flight per lane and
   // 8-wave workgroups were measured slower - DESIGN.md 4.11a - and are no longer instantiated.)
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 2 * 4);
 #define TTASR_XA(NT_)                                                                                                                  \

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
   const bool forced = st.prompt && (step + 1 < plen);
   const bool want_ns = p.no_speech >= 0 && step == p.sot_index && st.no_speech;
   if (forced && !want_ns && !HOOK) {
+    // every wave of this workgroup has read *st.step before its ticket is drawn: the workgroup that draws the last ticket
+    // stores step + 1, and a slower wave must not see that value and leave this branch alone
+    __syncthreads();
     if (tid == 0) { st.cur_tok[b] = st.prompt[b * p.max_prompt + step + 1]; step_ticket(ticket, total_rows, st.step, step); }
     return;
   }

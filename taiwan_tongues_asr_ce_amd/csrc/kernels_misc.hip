@@ -166,9 +166,9 @@ template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int,
 // workgroup per CU) into this HBM-streaming kernel lets them run the plain "bias -> T" epilogue.  delta may alias `out`
 // (each lane reads its delta chunks before it writes the same positions of the output).
 template <typename T, int NV, bool ADD>  // NV = float4 per lane kept in registers: d <= 256 * NV
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* out, int rows, int d,
-                                                        const T* delta, float* __restrict__ x_out) {
+                                                        const T* delta, float* x_out /* ADD: the same rows as x */) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float4* xr = (const float4*)(x + (int64_t)row * d);

@@ -15,21 +15,47 @@ from . import synth
 from .config import WhisperDims
 
 
+def force_collectives() -> bool:
+    """TTASR_DIST_FORCE=1: run the process-group code paths (RCCL weight broadcast into device buckets, token / logits
+    all-gathers, barriers) even at WORLD_SIZE = 1 - RCCL accepts a single rank per device, so a 1-GPU box executes exactly
+    the transport calls an 8-GPU node will (tests/test_gpu_weights_and_launch.py, `bench.py --gpus 1`)."""
+    return os.environ.get("TTASR_DIST_FORCE", "") not in ("", "0")
+
+
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from the torchrun environment; no-op for a single process."""
+    """(rank, world, local_rank) from the torchrun environment; no-op for a single process unless force_collectives()."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:       # forced single-rank group started from a bare shell
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
         if backend is None:
             # TTASR_DIST_BACKEND=gloo: plumbing smoke test with several ranks sharing one GPU (RCCL refuses that)
             backend = os.environ.get("TTASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
         if backend == "nccl":
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local)   # binds the communicator to this rank's GPU at creation (eager init)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def barrier(device: Optional[int] = None):
+    """dist.barrier() that names the device under RCCL (otherwise the backend guesses it from the rank)."""
+    if not dist.is_initialized():
+        return
+    if dist.get_backend() == "nccl" and device is not None:
+        dist.barrier(device_ids=[device])
+    else:
+        dist.barrier()
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -44,18 +70,39 @@ def _is_matrix(name: str, shape) -> bool:
     return len(shape) >= 2 and name != "model.encoder.embed_positions.weight"
 
 
+def bucket_plan(sizes: Sequence[int], kinds: Sequence[int], bucket_bytes: int, esz: Sequence[int]) -> List[List[int]]:
+    """Tensors 0..n-1 (element counts `sizes`, dtype class `kinds[i]` with esz[kind] bytes per element) -> buckets of indices.
+    One bucket stays open PER dtype class and closes when the next tensor of its class would overflow bucket_bytes, so the
+    interleaving of bf16 matrices with f32 biases / LayerNorm vectors in the state-dict order does not cut the buckets short
+    (~800 one-tensor broadcasts for large-v3 became 14).  Buckets are returned in the order in which their
+    LAST tensor appears: rank 0, which receives the tensors in state-dict order, can send each bucket the moment it is complete
+    with at most one open bucket per class in memory."""
+    open_b = {}
+    done: List[List[int]] = []
+    fill = {}
+    for i, (n, k) in enumerate(zip(sizes, kinds)):
+        if k in open_b and (fill[k] + n) * esz[k] > bucket_bytes:
+            done.append(open_b.pop(k))
+        if k not in open_b:
+            open_b[k], fill[k] = [], 0
+        open_b[k].append(i)
+        fill[k] += n
+    done.extend(open_b.values())
+    done.sort(key=lambda b: b[-1])
+    return done
+
+
 def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, np.ndarray]]], device=None,
                       bucket_bytes: int = 256 << 20, bf16_matrices: bool = False) -> Iterator[Tuple[str, object]]:
-    """Rank 0 supplies (name, array) in tensor_specs order; every rank yields the same sequence.  Tensors travel in
-    ~256 MB buckets (few, large broadcasts: xGMI is point-to-point, so per-call latency and per-link bandwidth, not
-    switch fan-out, set the cost).
+    """Rank 0 supplies (name, array) in tensor_specs order; every rank yields every tensor once (bucket order - the engine's
+    intake is keyed by name).  Tensors travel in ~256 MB buckets, one open bucket per dtype (few, large broadcasts: xGMI is
+    point-to-point, so per-call latency and per-link bandwidth, not switch fan-out, set the cost).
 
     RCCL ("nccl") backend: the buckets live in device memory and are handed to the engine as DeviceTensor views - GPU to
     GPU over xGMI, no host staging on the receiving ranks; with `bf16_matrices` (bf16 engines) the weight matrices are
     rounded to bf16 ONCE on rank 0 and travel as bf16 (3.1 GB instead of 6.2 GB for large-v3; every rank, rank 0
     included, loads the same bits).  gloo backend (CPU tests): float32 host buckets, host arrays out."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         yield from src_iter
         return
     from .engine import DeviceTensor
@@ -63,47 +110,50 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
     on_dev = not (device is None or dist.get_backend() == "gloo")
     dev = torch.device(f"cuda:{device}") if on_dev else torch.device("cpu")
     specs = synth.tensor_specs(dims)
-    it = iter(src_iter) if rank == 0 else None
+    sizes = [int(np.prod(sp[1])) for sp in specs]
+    kinds = [1 if (on_dev and bf16_matrices and _is_matrix(sp[0], sp[1])) else 0 for sp in specs]
+    esz = (4, 2)
+    dts = (torch.float32, torch.bfloat16)
+    plan = bucket_plan(sizes, kinds, bucket_bytes, esz)
+    where = {}                                  # tensor index -> (bucket, element offset)
+    for b, idx in enumerate(plan):
+        off = 0
+        for k in idx:
+            where[k] = (b, off)
+            off += sizes[k]
+    flats = {}
 
-    def dtype_of(k):
-        return torch.bfloat16 if (on_dev and bf16_matrices and _is_matrix(specs[k][0], specs[k][1])) else torch.float32
+    def flat_of(b):
+        if b not in flats:
+            flats[b] = torch.empty(sum(sizes[k] for k in plan[b]), dtype=dts[kinds[plan[b][0]]], device=dev)
+        return flats[b]
 
-    i = 0
-    while i < len(specs):
-        dt = dtype_of(i)
-        esz = 2 if dt == torch.bfloat16 else 4
-        j, n_el = i, 0
-        while j < len(specs) and dtype_of(j) == dt and (j == i or (n_el + int(np.prod(specs[j][1]))) * esz <= bucket_bytes):
-            n_el += int(np.prod(specs[j][1]))
-            j += 1
-        if rank == 0:
-            flat = torch.empty(n_el, dtype=dt, device=dev)
-            off = 0
-            for k in range(i, j):
-                name, arr = next(it)
-                assert name == specs[k][0] and tuple(arr.shape) == tuple(specs[k][1]), (name, specs[k])
-                n = int(np.prod(specs[k][1]))
-                flat[off:off + n] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).ravel()).to(dev).to(dt)
-                off += n
-        else:
-            flat = torch.empty(n_el, dtype=dt, device=dev)
+    def emit(b):
+        flat = flats.pop(b)
         dist.broadcast(flat, src=0)
+        k0 = kinds[plan[b][0]]
         if on_dev:
-            torch.cuda.synchronize(dev)   # the engine reads the bucket on its own stream
-            off = 0
-            for k in range(i, j):
-                n = int(np.prod(specs[k][1]))
-                yield specs[k][0], DeviceTensor(flat.data_ptr() + off * esz, 1 if dt == torch.bfloat16 else 0, tuple(specs[k][1]))
-                off += n
-            del flat                      # the consumer has loaded every view (load_weights is synchronous)
+            torch.cuda.synchronize(dev)       # the engine reads the bucket on its own stream
+            for k in plan[b]:
+                yield specs[k][0], DeviceTensor(flat.data_ptr() + where[k][1] * esz[k0], k0, tuple(specs[k][1]))
         else:
             host = flat.numpy()
-            off = 0
-            for k in range(i, j):
-                n = int(np.prod(specs[k][1]))
-                yield specs[k][0], host[off:off + n].reshape(specs[k][1])
-                off += n
-        i = j
+            for k in plan[b]:
+                yield specs[k][0], host[where[k][1]:where[k][1] + sizes[k]].reshape(specs[k][1])
+        del flat                              # the consumer has loaded every view (load_weights is synchronous)
+
+    if rank == 0:
+        closes = {idx[-1]: b for b, idx in enumerate(plan)}
+        for k, (name, arr) in enumerate(src_iter):
+            assert name == specs[k][0] and tuple(arr.shape) == tuple(specs[k][1]), (name, specs[k])
+            b, off = where[k]
+            flat_of(b)[off:off + sizes[k]] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32).ravel()).to(dev).to(dts[kinds[k]])
+            if k in closes:
+                yield from emit(closes[k])
+    else:
+        for b in range(len(plan)):
+            flat_of(b)
+            yield from emit(b)
 
 
 def broadcast_weights(engine, dims: WhisperDims, src_iter, device=None):
@@ -118,7 +168,7 @@ def gather_tokens(tokens: Sequence[Sequence[int]], max_len: int, device=None, pa
     for b, t in enumerate(tokens):
         n = min(len(t), max_len)
         local[b, :n] = t[:n]
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local
     dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
     mine = torch.from_numpy(local).to(dev)
@@ -132,7 +182,7 @@ def gather_logits(logits: np.ndarray, device=None) -> np.ndarray:
     [world][rows][vocab] array on every rank.  Used to prove the broadcast weights are bit-identical everywhere: all
     ranks decode the same probe clip and must produce the same logits."""
     local = np.ascontiguousarray(logits, dtype=np.float32)
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return local[None]
     dev = torch.device("cpu") if device is None or dist.get_backend() == "gloo" else torch.device(f"cuda:{device}")
     mine = torch.from_numpy(local).to(dev)

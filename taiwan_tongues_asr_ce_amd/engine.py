@@ -157,6 +157,11 @@ class Engine:
         assert mel.shape[1:] == (self.dims.n_mels, 2 * self.audio_ctx), mel.shape
         self._check(self.lib.ttasr_set_mel(self.h, _ptr(mel), mel.shape[0]), "set_mel")
 
+    def set_option(self, key: str, value: int):
+        """Kernel-selection override for tests / A-B measurements (ttasr_set_option; keys in include/ttasr.h).  The library
+        reads no environment variable: this call is the only way to leave the measured configuration."""
+        self._check(self.lib.ttasr_set_option(self.h, key.encode(), int(value)), f"set_option({key})")
+
     # -- a6..a8 --------------------------------------------------------------------------------
     def encode(self, B: int, want_output: bool = False) -> Optional[np.ndarray]:
         out = np.empty((B, self.audio_ctx, self.dims.d_model), dtype=np.float32) if want_output else None
@@ -300,6 +305,12 @@ class Engine:
         a = (C.c_float * 4)()
         self._check(self.lib.ttasr_phase_ms(self.h, a), "phase_ms")
         return dict(mel=a[0], encoder=a[1], cross_kv=a[2], decode=a[3])
+
+    def encoder_kernel_ms(self) -> Dict[str, float]:
+        """Per-class in-situ times of the last encode() run with option enc_kernel_timing = 1 (ttasr_encoder_kernel_ms)."""
+        a = (C.c_float * 8)()
+        self._check(self.lib.ttasr_encoder_kernel_ms(self.h, a), "encoder_kernel_ms")
+        return dict(zip(("conv", "layernorm", "qkv", "attention", "out_proj", "fc1", "fc2", "cross_kv"), (float(v) for v in a)))
 
     def bench_kernel(self, name: str, B: int, iters: int = 20) -> Dict[str, float]:
         ms, by, fl = C.c_float(), C.c_double(), C.c_double()

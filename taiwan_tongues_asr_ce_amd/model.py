@@ -507,6 +507,9 @@ class WhisperModel:
         n_frames = len(audio) // HOP
         if n_frames <= 0:
             return 0.0
+        # the seeks below step by the model's FULL window: a reduced audio context left behind by transcribe_windows(audio_ctx=...)
+        # would make every call cover only part of its 3000 frames and the maximum miss most of the recording
+        self.engine.set_audio_ctx(0)
         seeks = list(range(0, n_frames, self.dims.n_frames))
         best = -np.inf
         for i in range(0, len(seeks), self.max_batch):
@@ -675,18 +678,21 @@ class WhisperModel:
         lang_tok = self._lang_token(language)
         prev = self.tokenizer.encode(" " + initial_prompt.strip()) if initial_prompt else []
         out: List[Tuple[str, float]] = []
-        for i in range(0, len(clips), per_pass):
-            chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + per_pass]]
-            eng.set_audio_ctx(self._pick_audio_ctx(audio_ctx, max(len(c) for c in chunk)))
-            eng.log_mel(chunk, want_output=False)
-            eng.encode(len(chunk))
-            prompt, sot_index = self._prompt(lang_tok, "transcribe", without_timestamps, prev)
-            opts = eng.gen_opts(min(max_new_tokens, self.dims.n_text_ctx - len(prompt)), timestamps=not without_timestamps,
-                                sot_index=sot_index)
-            res = eng.generate_beam([prompt] * len(chunk), beam, opts) if beam > 1 else eng.generate([prompt] * len(chunk), opts)
-            for c, toks in zip(chunk, res.tokens):
-                toks = [t for t in toks if t != st.eot]
-                ts = [t for t in toks if t >= st.timestamp_begin]
-                end = (ts[-1] - st.timestamp_begin) * 0.02 if ts else len(c) / SAMPLE_RATE
-                out.append((self.tokenizer.decode([t for t in toks if t < st.eot]), float(end)))
+        try:
+            for i in range(0, len(clips), per_pass):
+                chunk = [np.ascontiguousarray(c[: self.n_window], dtype=np.float32) for c in clips[i:i + per_pass]]
+                eng.set_audio_ctx(self._pick_audio_ctx(audio_ctx, max(len(c) for c in chunk)))
+                eng.log_mel(chunk, want_output=False)
+                eng.encode(len(chunk))
+                prompt, sot_index = self._prompt(lang_tok, "transcribe", without_timestamps, prev)
+                opts = eng.gen_opts(min(max_new_tokens, self.dims.n_text_ctx - len(prompt)), timestamps=not without_timestamps,
+                                    sot_index=sot_index)
+                res = eng.generate_beam([prompt] * len(chunk), beam, opts) if beam > 1 else eng.generate([prompt] * len(chunk), opts)
+                for c, toks in zip(chunk, res.tokens):
+                    toks = [t for t in toks if t != st.eot]
+                    ts = [t for t in toks if t >= st.timestamp_begin]
+                    end = (ts[-1] - st.timestamp_begin) * 0.02 if ts else len(c) / SAMPLE_RATE
+                    out.append((self.tokenizer.decode([t for t in toks if t < st.eot]), float(end)))
+        finally:
+            eng.set_audio_ctx(0)   # never leave a reduced window behind: the file-level paths assume the model's 30-s window
         return out

@@ -1,0 +1,69 @@
+"""Shared checkers for the GPU parity tests (test infrastructure: imports oracle/).
+
+teacher_forced(): feed the oracle the ENGINE's tokens and grade every choice of the engine against the oracle's processed
+logits at that step -
+  * the chosen token is allowed and within `tol` of the oracle's best allowed logit;
+  * wherever the oracle's own top-2 margin exceeds `margin` (= 2 x the logit tolerance of the compute mode) the token must
+    BE the oracle's argmax (token equality under margin);
+and count how many steps carried such a clear margin, so callers can assert the test is not vacuous."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from oracle import whisper_ref as R
+
+
+@dataclass
+class Graded:
+    n_steps: int = 0
+    n_clear: int = 0          # steps whose oracle margin exceeded `margin` (held to token equality)
+    worst: float = 0.0        # largest (best allowed logit - chosen logit)
+
+    def add(self, other: "Graded"):
+        self.n_steps += other.n_steps
+        self.n_clear += other.n_clear
+        self.worst = max(self.worst, other.worst)
+
+
+def encode_chunked(mel: np.ndarray, W, rd, chunk: int = 4) -> torch.Tensor:
+    """Oracle encoder over a batch in chunks (the [B, H, T, T] score tensor of a 30-s window is 180 MB per clip at 20 heads)."""
+    outs = [R.encoder_forward(torch.from_numpy(mel[i:i + chunk]), W, rd) for i in range(0, len(mel), chunk)]
+    return torch.cat(outs, dim=0)
+
+
+def teacher_forced(tokens: Sequence[Sequence[int]], prompt: Sequence[int], enc_ref: torch.Tensor, W, rd, rules, tol: float,
+                   margin: float, n_check: int | None = None) -> Graded:
+    """Grade rows `tokens[b]` (engine output for clip b of enc_ref) as described in the module docstring."""
+    B = len(tokens)
+    assert enc_ref.shape[0] == B
+    xkv = R.cross_kv(enc_ref, W, rd)
+    cache = R.SelfCache.empty(rd.dec_layers)
+    logits = None
+    for t in prompt:
+        logits = R.decoder_forward(torch.full((B, 1), int(t), dtype=torch.long), cache, xkv, W, rd)[:, 0]
+    n = min(len(t) for t in tokens)
+    if n_check is not None:
+        n = min(n, n_check)
+    g = Graded()
+    for i in range(n):
+        nxt: List[int] = []
+        for b in range(B):
+            s = np.asarray(R.apply_rules(logits[b], list(tokens[b][:i]), rules))
+            c = int(tokens[b][i])
+            assert s[c] > -np.inf, f"row {b} step {i}: the engine chose a masked token ({c})"
+            gap = float(s.max() - s[c])
+            assert gap < tol, f"row {b} step {i}: chosen logit {gap:.4f} below the oracle's best (tolerance {tol})"
+            g.worst = max(g.worst, gap)
+            top2 = np.partition(s, -2)[-2:]
+            if top2[1] - top2[0] > margin:
+                assert int(np.argmax(s)) == c, f"row {b} step {i}: token {c} != oracle argmax {int(np.argmax(s))} at a clear margin"
+                g.n_clear += 1
+            g.n_steps += 1
+            nxt.append(c)
+        if i + 1 < n:
+            logits = R.decoder_forward(torch.tensor(nxt, dtype=torch.long)[:, None], cache, xkv, W, rd)[:, 0]
+    return g

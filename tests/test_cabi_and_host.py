@@ -31,6 +31,14 @@ def test_header_symbols_exported(lib):
     assert b"gfx950" in lib.ttasr_version()
 
 
+def test_release_library_has_no_environment_switch(lib):
+    """Every kernel-selection override is an explicit ttasr_set_option call; the shipped library holds no TTASR_* switch name
+    (`strings libttasr.so | grep TTASR_` is empty).  -DTTASR_EXPERIMENTS builds bring the lab switches back."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"TTASR_" not in blob
+    assert lib.ttasr_set_option(None, b"flash", 0) == -1       # NULL context: refused, no crash
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.Config) == 12 * 4
     assert ctypes.sizeof(_lib.GenOpts) == 12 * 4 + 2 * ctypes.sizeof(ctypes.c_void_p)
@@ -241,3 +249,72 @@ def test_default_suppress_list_has_startoflm_like_the_reference():
         assert st.eot not in ids and st.no_timestamps not in ids and all(i < st.timestamp_begin for i in ids)
     st = SpecialTokens.for_vocab(512)                          # synthetic vocabularies have no <|startoflm|>
     assert st.sot_lm == -1 and -1 not in default_suppress(st, 512)
+
+
+class _CtxEngine:
+    """Engine double that records the audio-context calls and answers the feature calls of the file-level path."""
+
+    def __init__(self, full):
+        self.full, self.ctx, self.calls = full, full, []
+
+    def set_audio_ctx(self, n=0):
+        self.ctx = n or self.full
+        self.calls.append(("ctx", self.ctx))
+
+    def log_mel_windows(self, audio, seeks, floor_max=None, want_output=False, want_max=False):
+        self.calls.append(("windows", self.ctx, list(seeks)))
+        return None, np.zeros(len(seeks), np.float32)
+
+
+def test_file_feature_max_never_runs_on_a_reduced_audio_context():
+    """transcribe_windows(audio_ctx=...) used to leave the engine on a short window; the next
+    file-level call then took the whole-file maximum over a fraction of every 30-s window.  _file_feature_max restores the
+    model's window first, and transcribe_windows restores it on the way out (also when a pass raises)."""
+    m = _bare_model()
+    m.max_batch = 4
+    m.engine = _CtxEngine(m.dims.n_audio_ctx)
+    m.engine.set_audio_ctx(150)                                   # what an earlier short-window pass left behind
+    m._file_feature_max(np.zeros(16000 * 70, np.float32))
+    feature_calls = [c for c in m.engine.calls if c[0] == "windows"]
+    assert feature_calls and all(c[1] == m.dims.n_audio_ctx for c in feature_calls)
+    assert feature_calls[0][2] == [0, 3000, 6000]
+
+    class Boom(_CtxEngine):
+        def log_mel(self, *a, **k):
+            raise RuntimeError("boom")
+    m.engine = Boom(m.dims.n_audio_ctx)
+    m.n_window = 480000
+    m.tokenizer = type("T", (), {"encode": staticmethod(lambda s: []), "decode": staticmethod(lambda t: "")})()
+    with pytest.raises(RuntimeError):
+        m.transcribe_windows([np.zeros(48000, np.float32)], audio_ctx=150, beam_size=1)
+    assert m.engine.ctx == m.dims.n_audio_ctx and m.engine.calls[-1] == ("ctx", m.dims.n_audio_ctx)
+
+
+def test_adapter_retries_without_vad_only_when_a_vad_source_is_configured():
+    """faster_whisper_asr.py:186-196: an empty result with vad_filter=True is retried once with VAD off.  Here the retry is
+    live only when a VAD source exists (without one vad_filter=True already keeps the whole clip)."""
+    import asyncio
+    from taiwan_tongues_asr_ce_amd.asr import MI355XWhisperASR
+
+    class Seg:
+        def __init__(self, text):
+            self.text, self.start, self.end, self.words = text, 0.0, 1.0, None
+
+    class Pipe:
+        def __init__(self, prob_fn):
+            self.vad_speech_prob_fn, self.calls = prob_fn, []
+
+        def transcribe(self, audio, **kw):
+            self.calls.append(kw["vad_filter"])
+            return iter([] if kw["vad_filter"] else [Seg("重試成功")]), type("I", (), {"language": "zh", "language_probability": 1.0})()
+
+    client = type("C", (), {"scratch_buffer": (np.zeros(1600, "<i2")).tobytes(), "last_start_time": 0})()
+    for prob_fn, want_calls, want_text in ((lambda a: np.zeros(4), [True, False], "重試成功"), (None, [True], None)):
+        a = object.__new__(MI355XWhisperASR)
+        a.asr_pipeline = Pipe(prob_fn)
+        a.default_transcribe_kwargs = {"word_timestamps": False, "vad_filter": True, "beam_size": 5,
+                                       "condition_on_previous_text": True, "initial_prompt": "繁體中文"}
+        a.text_filter = None
+        out = asyncio.run(a.transcribe(client))
+        assert a.asr_pipeline.calls == want_calls
+        assert (out["text"] if out else None) == want_text

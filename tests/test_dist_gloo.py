@@ -113,3 +113,55 @@ def test_folder_tool_shards_files_across_ranks(tmp_path):
     assert [d["asr_result"] for d in on_disk["detailed_results"]] == [f"長度{n}0" for n in (11, 12, 13, 14, 15)]
     for n in names:
         assert (folder / (n[:-4] + "_asr.txt")).exists()
+
+
+def test_bucket_plan_keeps_one_open_bucket_per_dtype():
+    """the state-dict order interleaves bf16 matrices with f32 vectors; buckets are per dtype, few and large,
+    every tensor lands in exactly one, and the order of the buckets is the order in which rank 0 completes them."""
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import PRESETS
+    from taiwan_tongues_asr_ce_amd.dist import _is_matrix, bucket_plan
+    specs = synth.tensor_specs(PRESETS["large-v3"])
+    sizes = [int(np.prod(s[1])) for s in specs]
+    kinds = [1 if _is_matrix(s[0], s[1]) else 0 for s in specs]
+    plan = bucket_plan(sizes, kinds, 256 << 20, (4, 2))
+    assert sorted(k for b in plan for k in b) == list(range(len(specs)))
+    assert len(plan) <= 16                                               # was ~800 when a bucket ended at every dtype change
+    for b in plan:
+        assert len({kinds[k] for k in b}) == 1 and b == sorted(b)
+        assert sum(sizes[k] for k in b) * (2 if kinds[b[0]] else 4) <= (256 << 20) or len(b) == 1
+    assert [b[-1] for b in plan] == sorted(b[-1] for b in plan)
+    # one dtype (gloo / f32 engines): plain consecutive runs
+    plan1 = bucket_plan(sizes[:40], [0] * 40, 1 << 20, (4, 2))
+    assert [k for b in plan1 for k in b] == list(range(40))
+
+
+def _forced_single_rank(q):
+    os.environ.update(TTASR_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    os.environ.pop("MASTER_PORT", None)
+    import torch.distributed as dist
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import PRESETS
+    from taiwan_tongues_asr_ce_amd.dist import barrier, broadcast_tensors, gather_logits, gather_tokens, init_process_group
+    r, w, _ = init_process_group("gloo")
+    dims = PRESETS["micro"]
+    got = dict(broadcast_tensors(dims, synth.iter_weights(dims), bucket_bytes=1 << 18))
+    ref = synth.state_dict(dims)
+    ok = dist.is_initialized() and (r, w) == (0, 1) and set(got) == set(ref) and all(np.array_equal(got[k], ref[k]) for k in ref)
+    ok = ok and gather_tokens([[1, 2], [3]], 3).tolist() == [[1, 2, -1], [3, -1, -1]]
+    ok = ok and gather_logits(np.ones((2, 5), np.float32)).shape == (1, 2, 5)
+    barrier()
+    dist.destroy_process_group()
+    q.put(ok)
+
+
+def test_forced_single_rank_group_runs_the_collective_paths():
+    """TTASR_DIST_FORCE=1: the process-group code (bucketed broadcast, gathers, barrier) runs at WORLD_SIZE = 1 - the switch the
+    GPU suite uses to execute the RCCL transport on a one-GPU box."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_single_rank, args=(q,))
+    p.start()
+    assert q.get(timeout=180) is True
+    p.join(60)
+    assert p.exitcode == 0

@@ -1,7 +1,8 @@
-"""GPU, BASELINE.json's full configuration (whisper-large-v3 geometry, 32+32 layers, B = 32, bf16, 128 new tokens):
-the oracle cannot run this in test time, so the checks are size-independent properties of the path —
-the logits-processor invariants on every emitted token, finite scores, batch-composition independence of a row,
-clip-order equivariance, beam(1) == greedy, and that a clip transcribed alone reproduces its row of the batch."""
+"""GPU, BASELINE.json's full configuration (whisper-large-v3 geometry, 32+32 layers, B = 32, bf16, 128 new tokens).
+The oracle cannot run all of it in test time, so: (i) size-independent properties of the whole batch - the
+logits-processor invariants on every emitted token, finite scores, bit-identical replays, clip-order equivariance;
+(ii) four ROWS of the B = 32 batch recomputed by the CPU oracle at full depth (prompt logits within 0.08, teacher-forced
+token equality under margin), also for a clip decoded alone and by beam(1); (iii) one clip end to end in f32 (1e-3) and bf16."""
 import numpy as np
 import pytest
 
@@ -20,19 +21,6 @@ def eng():
     e.load_weights(synth.iter_weights(dims))
     yield e
     e.close()
-
-
-def _agree(a, b):
-    n = min(len(a), len(b))
-    return sum(x == y for x, y in zip(a[:n], b[:n])) / max(n, 1)
-
-
-def _same_prefix_fraction(rows_a, rows_b, k):
-    """Fraction of rows whose first k tokens agree (used where the two runs go through DIFFERENT kernels - a clip alone
-    takes other GEMM tiles than the same clip inside a batch of 32 - so the last bits of the logits differ and a near-tie
-    of the random-init weights can flip).  Replays and re-orderings of the same batch are held to exact equality: the
-    bf16 path has no float atomics (K-split partial tiles are summed in a fixed order)."""
-    return float(np.mean([a[:k] == b[:k] for a, b in zip(rows_a, rows_b)]))
 
 
 def test_full_size_invariants(eng):
@@ -72,19 +60,74 @@ def test_full_size_invariants(eng):
     assert rev.tokens[::-1] == res.tokens
     assert np.array_equal(rev.sum_logprob[::-1], res.sum_logprob)
     assert np.array_equal(rev.no_speech_prob[::-1], res.no_speech_prob)
-    # a clip alone (B = 1: split cross-attention, 256x128 GEMM tiles) == its row in the batch of 32, early tokens
-    solo_rows, batch_rows = [], []
+    # a clip alone (B = 1: split cross-attention, 256x128 GEMM tiles) and beam search with ONE hypothesis take other kernels
+    # than the batch of 32, so the last bits of their logits differ and a near-tie of the random-init weights may flip: all
+    # three routes are graded against the ORACLE below (test_full_depth_b32_rows_teacher_forced_against_the_oracle), not
+    # against each other; here only their structural properties
     for b in (5, 17, 30):
         e.log_mel([clips[b]], want_output=False)
         e.encode(1)
-        solo_rows.append(e.generate([prompt], e.gen_opts(16, True, suppress_eot=True)).tokens[0])
-        batch_rows.append(res.tokens[b])
-    assert _same_prefix_fraction(solo_rows, batch_rows, 4) >= 2 / 3
-    # beam search with one hypothesis is greedy search (first tokens; scores accumulate in different precision)
-    e.log_mel([clips[b] for b in (5, 17, 30)], want_output=False)
-    e.encode(3)
-    beam1 = e.generate_beam([prompt] * 3, 1, e.gen_opts(16, True, suppress_eot=True))
-    assert _same_prefix_fraction(beam1.tokens, solo_rows, 4) >= 2 / 3
+        solo = e.generate([prompt], e.gen_opts(16, True, suppress_eot=True)).tokens[0]
+        assert len(solo) == 16 and solo[0] >= st.timestamp_begin and not sup.intersection(solo)
+
+
+@pytest.fixture(scope="module")
+def oracle_full():
+    """Full-depth large-v3 weights for the oracle, bf16-rounded (what the bf16 engine holds): one generation per module."""
+    import torch
+    from oracle import whisper_ref as R
+    torch.set_grad_enabled(False)
+    dims = PRESETS["large-v3"]
+    return R.Dims(**dims.as_dict()), R.to_torch(synth.state_dict(dims), round_bf16=True)
+
+
+def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full):
+    """The MEASURED configuration held to the oracle: whisper-large-v3 geometry, 32 + 32 layers,
+    B = 32 different clips, bf16 - i.e. the single-pass cross-attention kernel, the identity-page self-attention and the 32-row
+    decode GEMMs exactly as bench.py runs them.  Four rows of the batch (first, last, two inside) are recomputed by the CPU
+    oracle (bf16-rounded weights; ~4 s of encoder each on the box's host): the step-API logits of the four prompt positions
+    are within 0.08, and under teacher forcing each of the first 4 greedy tokens of the B = 32 generate() is within 0.15 of the
+    oracle's best allowed logit and IS the oracle's token wherever its top-2 margin exceeds 0.16.  The same rows decoded ALONE
+    (B = 1: frame-split cross-attention, other GEMM tiles) and by beam search with one hypothesis pass the same grading."""
+    import torch
+    from oracle import whisper_ref as R
+    from oracle_checks import Graded, teacher_forced
+    from taiwan_tongues_asr_ce_amd.engine import default_suppress
+    e = eng
+    st = e.special
+    rd, Wb = oracle_full
+    clips = [synth.noise_clip(i) if i % 3 else synth.tonal_clip(i) for i in range(B)]
+    rows = (0, 5, 17, 31)
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    e.log_mel(clips, want_output=False)
+    e.encode(B)
+    e.decode_reset(B)
+    step_logits = [e.decode_step([t] * B) for t in prompt]               # B = 32 rows through the step API (same kernels)
+    opts = e.gen_opts(8, False, check_interval=1 << 20)
+    res = e.generate([prompt] * B, opts)                                 # the benchmark's route: graph replay, K-split slabs
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False)
+    mel = np.stack([R.log_mel(clips[b], e.dims.n_mels) for b in rows])
+    total, solo_total = Graded(), Graded()
+    for k, b in enumerate(rows):
+        enc_ref = R.encoder_forward(torch.from_numpy(mel[k:k + 1]), Wb, rd)
+        xkv = R.cross_kv(enc_ref, Wb, rd)
+        cache = R.SelfCache.empty(rd.dec_layers)
+        for t, lg in zip(prompt, step_logits):
+            want = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[0, 0].numpy()
+            assert float(np.abs(lg[b] - want).max()) < 0.08, (b, t)
+        total.add(teacher_forced([res.tokens[b]], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16, n_check=4))
+        if b in (5, 17):   # the same clip alone, greedy and beam(1)
+            e.log_mel([clips[b]], want_output=False)
+            e.encode(1)
+            solo = e.generate([prompt], e.gen_opts(4, False)).tokens[0]
+            beam1 = e.generate_beam([prompt], 1, e.gen_opts(4, False)).tokens[0]
+            solo_total.add(teacher_forced([solo], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16))
+            solo_total.add(teacher_forced([[t for t in beam1 if t != st.eot]], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16))
+            e.log_mel(clips, want_output=False)                           # restore the batch for the next row's comparison
+            e.encode(B)
+    assert total.n_steps == 16 and total.n_clear >= 8, total              # not vacuous: most steps carried a clear margin
+    assert solo_total.n_clear >= 4, solo_total
 
 
 def test_full_depth_f32_parity_one_clip():
@@ -128,7 +171,7 @@ def test_full_depth_f32_parity_one_clip():
     assert res.tokens == ref.tokens
 
 
-def test_full_depth_bf16_against_oracle_with_rounded_weights():
+def test_full_depth_bf16_against_oracle_with_rounded_weights(oracle_full):
     """Same full model in the MEASURED mode (bf16): against the f32 oracle holding the bf16-rounded weights the encoder
     output stays within 0.06 (measured 0.023 max, 0.0026 mean on LayerNorm-scale values) and the prompt logits within
     0.08 (measured 0.032 on logits of std 1.8); under teacher forcing every greedy choice is within 0.15 of the oracle's
@@ -139,10 +182,9 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights():
     from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
     torch.set_grad_enabled(False)
     dims = PRESETS["large-v3"]
-    rd = R.Dims(**dims.as_dict())
-    sd = synth.state_dict(dims)
+    rd, Wb = oracle_full
     e = Engine(dims, COMPUTE_BF16, 1)
-    e.load_weights(sd.items())
+    e.load_weights(synth.iter_weights(dims))
     st = e.special
     clip = synth.tonal_clip(2)
     e.log_mel([clip], want_output=False)
@@ -152,8 +194,6 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights():
     step_logits = [e.decode_step([t]) for t in prompt]
     toks = e.generate([prompt], e.gen_opts(8, False)).tokens[0]
     e.close()
-    Wb = R.to_torch(sd, round_bf16=True)
-    del sd
     enc_ref = R.encoder_forward(torch.from_numpy(R.log_mel(clip, dims.n_mels)[None]), Wb, rd)
     err = np.abs(enc - enc_ref.numpy())
     assert err.max() < 0.06 and err.mean() < 0.006
@@ -177,3 +217,74 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights():
         assert s[t] > -np.inf and float(s.max() - s[t]) < 0.15, i
         logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[:, 0]
     assert n_clear >= 1
+
+
+def test_full_depth_beam5_eight_clips_properties_and_oracle_scores(oracle_full):
+    """Config C5's per-GPU share at FULL depth: whisper-large-v3, 32 + 32 layers, bf16, 8 clips x
+    beam 5 = 40 decode rows (the shared-clip cross-attention kernel, re-indexed page tables, two row groups per weight stream),
+    at Whisper's 30-s window and at the opt-in short window (150 positions = 3-s utterances, the streaming path).
+    Properties: rule invariants on every returned hypothesis, finite scores, bit-identical replay, clip-order equivariance
+    (a clip's 5 rows never interact with another clip's).  Oracle: the returned hypothesis of one clip is teacher-forced through
+    the CPU oracle (bf16-rounded weights) - the engine's cumulative log-probability matches the oracle's within 0.1 per token."""
+    import torch
+    from oracle import whisper_ref as R
+    from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
+    dims = PRESETS["large-v3"]
+    rd, Wb = oracle_full
+    A, beam, n_new = 8, 5, 10
+    e = Engine(dims, COMPUTE_BF16, A * beam)
+    e.load_weights(synth.iter_weights(dims))
+    st = e.special
+    prompt = [st.sot, st.lang_zh, st.transcribe]
+    full = [synth.noise_clip(200 + i) if i % 2 else synth.tonal_clip(200 + i) for i in range(A)]
+    short = [synth.noise_clip(300 + i, 48000) for i in range(A)]
+    for n_ctx, clips in ((0, full), (150, short)):
+        e.set_audio_ctx(n_ctx)
+        e.log_mel(clips, want_output=False)
+        e.encode(A)
+        opts = e.gen_opts(n_new, True)
+        sup = {opts.suppress[i] for i in range(opts.n_suppress)}
+        res = e.generate_beam([prompt] * A, beam, opts)
+        assert len(res.tokens) == A and np.isfinite(res.sum_logprob).all() and (res.sum_logprob <= 0).all()
+        assert ((res.no_speech_prob >= 0) & (res.no_speech_prob <= 1)).all()
+        for toks in res.tokens:
+            assert 0 < len(toks) <= n_new and all(0 <= t < dims.vocab for t in toks)
+            assert not sup.intersection(toks) and st.no_timestamps not in toks
+            assert st.timestamp_begin <= toks[0] <= st.timestamp_begin + 50
+            last = -1
+            for i, t in enumerate(toks):
+                if t >= st.timestamp_begin:
+                    assert t >= last
+                    last = t
+                if i >= 2 and toks[i - 1] >= st.timestamp_begin and toks[i - 2] >= st.timestamp_begin:
+                    assert t < st.timestamp_begin
+        again = e.generate_beam([prompt] * A, beam, opts)
+        assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
+        e.log_mel(clips[::-1], want_output=False)
+        e.encode(A)
+        rev = e.generate_beam([prompt] * A, beam, opts)
+        assert rev.tokens[::-1] == res.tokens and np.array_equal(rev.sum_logprob[::-1], res.sum_logprob)
+        if n_ctx == 0:     # oracle score of clip 3's hypothesis (one full-depth encoder pass on the host)
+            a = 3
+            rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                            suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=True)
+            enc_ref = R.encoder_forward(torch.from_numpy(R.log_mel(clips[a], dims.n_mels)[None]), Wb, rd)
+            xkv = R.cross_kv(enc_ref, Wb, rd)
+            cache = R.SelfCache.empty(rd.dec_layers)
+            logits = None
+            for t in prompt:
+                logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[:, 0]
+            total = 0.0
+            for i, t in enumerate(res.tokens[a]):
+                s = R.apply_rules(logits[0], res.tokens[a][:i], rules)
+                assert s[t] > -np.inf, (i, t)
+                total += float(torch.log_softmax(s, dim=-1)[t])
+                logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[:, 0]
+            n_scored = len(res.tokens[a])
+            # the engine's sum may include the final EOT's log-probability when the hypothesis ended (EOT is stripped from tokens)
+            slack = 0.1 * (n_scored + 1)
+            s_eot = float(torch.log_softmax(R.apply_rules(logits[0], res.tokens[a], rules), dim=-1)[st.eot])
+            got = float(res.sum_logprob[a])
+            assert min(abs(got - total), abs(got - (total + s_eot))) < slack, (got, total, s_eot)
+    e.set_audio_ctx(0)
+    e.close()

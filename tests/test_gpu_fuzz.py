@@ -114,21 +114,25 @@ def ctx_bf16():
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16
     from taiwan_tongues_asr_ce_amd.engine import Engine
     pd = PRESETS["tiny"]
-    e = Engine(pd, COMPUTE_BF16, 40)
+    e = Engine(pd, COMPUTE_BF16, 64)
     e.load_weights(synth.iter_weights(pd))
     Wb = R.to_torch(synth.state_dict(pd), round_bf16=True)
     yield e, pd, R.Dims(**pd.as_dict()), Wb
     e.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(12))
 def test_random_configuration_bf16_within_tolerance(ctx_bf16, seed):
-    """The measured (bf16) mode over random batch sizes 1..40, windows, prompts with a previous-text prefix and rule
-    sets: under teacher forcing every greedy choice is within 0.15 of the oracle's best allowed logit."""
+    """The measured (bf16) mode over random batch sizes 1..64, windows, prompts with a previous-text prefix and rule
+    sets: under teacher forcing every greedy choice is within 0.15 of the oracle's best allowed logit.  Seeds 8..11 force
+    B = 43 / 48 / 57 / 64: at tiny's 6 heads that is >= 256 (row, head) items, i.e. the single-pass cross-attention kernel
+    and two 32-row groups per weight stream in the decode GEMMs (below 43 rows the frame-split kernels run)."""
     e, pd, dims, Wb = ctx_bf16
     st = e.special
     rng = np.random.default_rng(5000 + seed)
     B = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 40]))
+    if seed >= 8:
+        B = (43, 48, 57, 64)[seed - 8]
     n_ctx = int(rng.choice([1500, 1500, 300, 750]))
     e.set_audio_ctx(n_ctx if n_ctx != 1500 else 0)
     base = [synth.noise_clip(int(rng.integers(0, 50)), n_ctx * 320), synth.tonal_clip(int(rng.integers(0, 50)))[: n_ctx * 320]]

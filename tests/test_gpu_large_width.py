@@ -79,9 +79,9 @@ def test_width_parity_f32_and_bf16(dims):
 
 
 @pytest.mark.gpu
-def test_flash_attention_matches_the_plain_attention_kernel_at_ragged_windows(monkeypatch):
+def test_flash_attention_matches_the_plain_attention_kernel_at_ragged_windows():
     """The MFMA flash kernel (kernels_flash.hip: 64-key tiles, last tile masked, softmax denominator summed by an all-ones
-    MFMA over the bf16-rounded weights) against the one-query-per-wave kernel (TTASR_NO_FLASH) on the same bf16 q, k, v:
+    MFMA over the bf16-rounded weights) against the one-query-per-wave kernel (option `flash = 0`) on the same bf16 q, k, v:
     the 2-layer encoder output agrees to bf16 rounding at windows that end inside a key tile (1500 = 23 x 64 + 28; 150),
     exactly on one (64, 128), on a single partial tile (20) and on an even tile count (200)."""
     from taiwan_tongues_asr_ce_amd.engine import Engine
@@ -90,9 +90,8 @@ def test_flash_attention_matches_the_plain_attention_kernel_at_ragged_windows(mo
     windows = (0, 20, 64, 128, 150, 200)
     outs = {}
     for plain in (False, True):
-        if plain:
-            monkeypatch.setenv("TTASR_NO_FLASH", "1")
         e = Engine(dims, COMPUTE_BF16, 3)
+        e.set_option("flash", 0 if plain else 1)
         e.load_weights(synth.iter_weights(dims))
         for n_ctx in windows:
             e.set_audio_ctx(n_ctx)

@@ -1,6 +1,6 @@
 """GPU: batched prompt prefill (previous-text / initial-prompt tokens computed in one pass) == feeding the prompt
 token by token.  f32: tokens exact vs the CPU oracle (which always feeds token by token) and vs the engine with
-TTASR_NO_PREFILL; bf16: same tokens' score within tolerance under the oracle's teacher forcing."""
+the `prefill = 0` option (ttasr_set_option); bf16: same tokens' score within tolerance under the oracle's teacher forcing."""
 import os
 
 import numpy as np
@@ -18,12 +18,9 @@ NAME = "tiny"
 
 def _engine(compute, max_batch, no_prefill=False):
     from taiwan_tongues_asr_ce_amd.engine import Engine
+    e = Engine(PRESETS[NAME], compute, max_batch)
     if no_prefill:
-        os.environ["TTASR_NO_PREFILL"] = "1"
-    try:
-        e = Engine(PRESETS[NAME], compute, max_batch)       # the switch is read at ttasr_create
-    finally:
-        os.environ.pop("TTASR_NO_PREFILL", None)
+        e.set_option("prefill", 0)                          # explicit test hook (ttasr_set_option): no environment switch
     e.load_weights(synth.iter_weights(PRESETS[NAME]))
     return e
 
@@ -144,8 +141,8 @@ def test_prefill_bf16_consistent_with_token_by_token(setup):
     e.close(); e_ref.close()
 
 
-def test_prefill_cross_attention_kernels_agree(setup, monkeypatch):
-    """The prefill pass has three cross-attention kernels: one workgroup per (row, head) (TTASR_NO_XSPLIT), groups of <= 8 rows
+def test_prefill_cross_attention_kernels_agree(setup):
+    """The prefill pass has three cross-attention kernels: one workgroup per (row, head) (option `xsplit = 0`), groups of <= 8 rows
     per clip sharing one K/V stream (2 <= rows per clip < 32 in bf16, any count in f32), and - bf16, >= 32 rows per clip - the
     MFMA flash pass with the rows as the M dimension.  A 70-token previous-text prompt (flash in bf16, groups in f32) and a
     12-token one (groups) must give the same greedy tokens as the per-row kernel, with total log-probabilities within rounding."""
@@ -154,11 +151,8 @@ def test_prefill_cross_attention_kernels_agree(setup, monkeypatch):
     for compute, tol in ((COMPUTE_F32, 2e-3), (COMPUTE_BF16, 0.25)):
         outs = {}
         for per_row in (False, True):
-            if per_row:
-                monkeypatch.setenv("TTASR_NO_XSPLIT", "1")
-            else:
-                monkeypatch.delenv("TTASR_NO_XSPLIT", raising=False)
             e = _engine(compute, 3)
+            e.set_option("xsplit", 0 if per_row else 1)
             st = e.special
             e.log_mel(clips, want_output=False)
             e.encode(3)
@@ -167,7 +161,6 @@ def test_prefill_cross_attention_kernels_agree(setup, monkeypatch):
                 prompt = _prev_prompt(st, rng, n_prev)
                 outs[per_row, n_prev] = e.generate([prompt] * 3, e.gen_opts(6, True, no_speech=False))
             e.close()
-        monkeypatch.delenv("TTASR_NO_XSPLIT", raising=False)
         for n_prev in (70, 12):
             a, b = outs[False, n_prev], outs[True, n_prev]
             for r in range(3):

@@ -79,3 +79,34 @@ def test_bench_launches_its_own_ranks():
     assert out["config"]["clips_per_gpu"] == 2
     assert out["config"]["rank_logits_spread"] == 0.0          # both ranks hold the same broadcast weights, bit for bit
     assert "share GPUs over gloo" in out["config"]["parallelism"]
+
+
+def test_rccl_transport_runs_on_one_rank():
+    """the on-device broadcast branch of dist.broadcast_tensors, the device-tensor gathers and the
+    RCCL barrier had never executed anywhere.  A ONE-rank "nccl" process group (TTASR_DIST_FORCE=1; RCCL accepts a single rank
+    per device) runs exactly those calls on this box: the engine loaded through the RCCL buckets is bit-identical (encoder
+    output, logits, tokens) to the engine loaded from host arrays, in bf16 (matrices travel as bf16) and f32."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TTASR_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_probe.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    for k in ("bf16_encoder_equal", "bf16_logits_equal", "bf16_tokens_equal", "f32_encoder_equal", "f32_logits_equal",
+              "f32_tokens_equal", "gather_tokens", "gather_logits", "broadcast_weights_runs"):
+        assert out[k] is True, (k, out)
+
+
+def test_bench_single_gpu_through_the_forced_rccl_group():
+    """`bench.py --gpus 1` with TTASR_DIST_FORCE=1: weights arrive through the RCCL broadcast, tokens leave through the RCCL
+    all-gather, the validation probe gathers first-step logits - and the spread across the (one) rank is exactly 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TTASR_DIST_BACKEND")}
+    env["TTASR_DIST_FORCE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "tiny", "--batch", "2",
+                        "--steps", "2", "--warmup", "1", "--new-tokens", "8", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["transport"] == "nccl"
+    assert out["config"]["rank_logits_spread"] == 0.0
+    assert out["output_check"]["replay_bit_identical"] is True

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Beam-search decode time on one GPU (large-v3 geometry, bf16): A clips x beam hypotheses, short prompt, N new tokens.
-One JSON line per configuration; TTASR_NO_XSPLIT=1 in the environment selects the one-workgroup-per-row cross-attention.
+One JSON line per configuration; `--option xsplit=0` selects the one-workgroup-per-row cross-attention (ttasr_set_option).
 
     python tools/beam_step_bench.py [--clips 6] [--beam 5] [--new-tokens 32]
 """
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--clips", default="1,6")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--new-tokens", type=int, default=32)
+    ap.add_argument("--option", action="append", default=[], help="key=value kernel-selection override (ttasr_set_option)")
     args = ap.parse_args()
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
@@ -32,6 +33,8 @@ def main():
     for A in [int(x) for x in args.clips.split(",")]:
         e = Engine(dims, COMPUTE_BF16, A * args.beam)
         e.load_weights(weights)
+        for kv in args.option:
+            e.set_option(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
         st = e.special
         e.log_mel([synth.noise_clip(b) for b in range(A)], want_output=False)
         e.encode(A)
@@ -47,7 +50,7 @@ def main():
         n_steps = max(len(t) for t in toks) + len(prompt)
         print(json.dumps({"clips": A, "beam": args.beam, "rows": A * args.beam, "wall_ms": round(min(ms[1:]), 2),
                           "steps_upper_bound": n_steps, "ms_per_step": round(min(ms[1:]) / n_steps, 3),
-                          "no_xsplit": bool(os.environ.get("TTASR_NO_XSPLIT"))}), flush=True)
+                          "options": args.option}), flush=True)
         e.close()
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the decode launch plans on one GPU (large-v3 geometry, B = 32, bf16, 4 + 128 greedy tokens):
-every variant is an environment setting read by ttasr_create, so one process times them all on the same clips.
+every variant is a set of ttasr_set_option overrides (the library reads no environment variable), so one process times
+them all on the same clips.
 Also checks that each variant is bit-reproducible (three replays give identical tokens and scores) and reports
 how many rows agree token-for-token between variants.  One JSON line per variant.
 
@@ -21,15 +22,16 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "auto": {},                                            # default plan: K slices chosen automatically (d 4, q 4, qkv 2, fc2 8)
-    "prefill_sot": {"TTASR_PREFILL_NS_MIN": "2"},
-    "d5": {"TTASR_KS": "5,5,2,8"},
-    "f16": {"TTASR_KS": "4,4,2,16"},
-    "f10": {"TTASR_KS": "4,4,2,10"},
-    "qkv4": {"TTASR_KS": "4,4,4,8"},
-    "w_plain": {"TTASR_W_NT": "0"},
-    "xattn_plain": {"TTASR_XATTN": "0"},
+    "prefill_sot": {"prefill_ns_min": 2},
+    "d5": {"ksplit_out": 5, "ksplit_q": 5, "ksplit_qkv": 2, "ksplit_fc2": 8},
+    "f16": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 16},
+    "f10": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 10},
+    "qkv4": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 4, "ksplit_fc2": 8},
+    "w_plain": {"weights_nontemporal": 0},
+    "xattn_plain": {"xattn_nontemporal": 0},
 }
-KNOBS = sorted({k for v in VARIANTS.values() for k in v})
+DEFAULTS = {"prefill_ns_min": 16, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
+            "xattn_nontemporal": 1}
 
 
 def main():
@@ -39,9 +41,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--reps", type=int, default=4)
-    ap.add_argument("--env", action="append", default=[], help="extra NAME=VALUE applied to every variant")
+    ap.add_argument("--option", action="append", default=[], help="extra key=value (ttasr_set_option) applied to every variant")
     ap.add_argument("--xattn-sweep", action="store_true",
-                    help="time the cross-attention kernel with nontemporal / plain loads (TTASR_XATTN 1 / 0) in isolation instead")
+                    help="time the cross-attention kernel with nontemporal / plain loads (option xattn_nontemporal 1 / 0) in isolation instead")
     args = ap.parse_args()
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
@@ -52,15 +54,13 @@ def main():
     clips = [synth.noise_clip(b) for b in range(B)]
     weights = list(synth.iter_weights(dims))
     if args.xattn_sweep:
-        import ctypes
         e = Engine(dims, COMPUTE_BF16, B)
         e.load_weights(weights)
         e.log_mel(clips, want_output=False)
         e.encode(B)
-        var = ctypes.c_int.in_dll(e.lib, "g_xattn_variant")
         for rep in range(2):
             for v in (1, 0):
-                var.value = v
+                e.set_option("xattn_nontemporal", v)
                 k = e.bench_kernel("xattn", B, iters=96)
                 print(json.dumps({"xattn_variant": v, "nontemporal": bool(v & 1), "us": round(k["ms"] * 1e3, 2),
                                   "TBps": round(k["bytes"] / k["ms"] / 1e9, 3)}), flush=True)
@@ -68,13 +68,12 @@ def main():
         return
     first = None
     for name in args.variants.split(","):
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update(VARIANTS[name])
-        for kv in args.env:
-            k, v = kv.split("=", 1)
-            os.environ[k] = v
         e = Engine(dims, COMPUTE_BF16, B)
+        for k, v in {**DEFAULTS, **VARIANTS[name]}.items():   # two of the options are process-wide: reset them per variant
+            e.set_option(k, v)
+        for kv in args.option:
+            k, v = kv.split("=", 1)
+            e.set_option(k, int(v))
         e.load_weights(weights)
         st = e.special
         e.log_mel(clips, want_output=False)
@@ -93,7 +92,7 @@ def main():
             first = runs[0]
         agree = float(np.mean([a == b for a, b in zip(first.tokens, runs[0].tokens)]))
         n_steps = 4 + args.new_tokens - 1
-        print(json.dumps({"variant": name, "env": VARIANTS[name], "decode_ms": round(min(ms[1:]), 2),
+        print(json.dumps({"variant": name, "options": VARIANTS[name], "decode_ms": round(min(ms[1:]), 2),
                           "ms_per_step": round(min(ms[1:]) / n_steps, 4), "wall_ms": round(min(wall[1:]), 2),
                           "bit_reproducible": bool(same), "rows_equal_to_first_variant": agree}), flush=True)
         e.close()

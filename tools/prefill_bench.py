@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long previous-text prompts (condition_on_previous_text): time of a greedy generate with a P-token prompt + N new tokens at
-B clips (large-v3 geometry, bf16).  TTASR_NO_XSPLIT=1 selects one cross-attention workgroup per (row, head) everywhere.
+B clips (large-v3 geometry, bf16).  `--option xsplit=0` selects one cross-attention workgroup per (row, head) everywhere (ttasr_set_option).
 
     python tools/prefill_bench.py [--batch 8] [--prompt 224] [--new-tokens 32]
 """
@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", default="1,8")
     ap.add_argument("--prompt", default="24,224")
     ap.add_argument("--new-tokens", type=int, default=32)
+    ap.add_argument("--option", action="append", default=[], help="key=value kernel-selection override (ttasr_set_option)")
     args = ap.parse_args()
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
@@ -32,6 +33,8 @@ def main():
     for B in [int(x) for x in args.batch.split(",")]:
         e = Engine(dims, COMPUTE_BF16, B)
         e.load_weights(weights)
+        for kv in args.option:
+            e.set_option(kv.split("=", 1)[0], int(kv.split("=", 1)[1]))
         st = e.special
         e.log_mel([synth.noise_clip(b) for b in range(B)], want_output=False)
         e.encode(B)
@@ -46,7 +49,7 @@ def main():
                 assert toks is None or r.tokens == toks
                 toks = r.tokens
             print(json.dumps({"batch": B, "prompt_tokens": P, "new_tokens": args.new_tokens, "wall_ms": round(min(ms[1:]), 2),
-                              "no_xsplit": bool(os.environ.get("TTASR_NO_XSPLIT"))}), flush=True)
+                              "options": args.option}), flush=True)
         e.close()
 
 
