@@ -36,6 +36,9 @@ extern "C" {
 
 #define TTASR_COMPUTE_F32 0    /* f32 weights+activations, exact-f32 MFMA: the 1e-3 parity mode */
 #define TTASR_COMPUTE_BF16 1   /* bf16 weights+activations, f32 accumulate/LN/softmax: throughput mode */
+#define TTASR_COMPUTE_F16 2    /* fp16 weights+activations, f32 accumulate/LN/softmax/residual stream: the reference's GPU regime
+                                * (compute_type="float16": asr_core.py:141, api/config.py:12, faster_whisper_asr.py:95); same
+                                * kernels and schedules as bf16 with the f16 MFMA forms, 3 more mantissa bits */
 
 typedef struct ttasr_ctx ttasr_ctx;
 
@@ -92,11 +95,13 @@ const char* ttasr_version(void);
 int ttasr_load_tensor(ttasr_ctx* ctx, const char* name, const float* data_host, const int64_t* dims, int32_t ndim);
 /* The same for a tensor that is already in DEVICE memory of this context's GPU (e.g. the bucket an RCCL broadcast just
  * filled: multi-GPU start-up moves every weight GPU-to-GPU over xGMI, in bf16 where the engine stores bf16, and never
- * stages it through a host): data_dev holds float32 (TTASR_DTYPE_F32) or raw bfloat16 bits (TTASR_DTYPE_BF16) in the
+ * stages it through a host): data_dev holds float32 (TTASR_DTYPE_F32), raw bfloat16 bits (TTASR_DTYPE_BF16) or IEEE half bits
+ * (TTASR_DTYPE_F16) in the
  * HF layout.  Must be complete (the caller's stream synchronised) when the call is made.  The reference's
  * WhisperModel(..., device="cuda") does this copy inside CTranslate2 (asr_core.py:141). */
 #define TTASR_DTYPE_F32 0
 #define TTASR_DTYPE_BF16 1
+#define TTASR_DTYPE_F16 2
 int ttasr_load_tensor_device(ttasr_ctx* ctx, const char* name, const void* data_dev, int32_t dtype, const int64_t* dims,
                              int32_t ndim);
 /* Checks every tensor arrived; must precede any compute call. */

@@ -235,17 +235,28 @@ def golden_align():
 
 
 def golden_bf16():
+    _golden_lowp(torch.bfloat16, "tiny_bf16.npz", "tiny bf16")
+
+
+def golden_f16():
+    """Golden set G7: as G5 with every parameter cast to float16 and HF's own fp16 arithmetic - exactly the precision regime the
+    reference's GPU call sites ask for (compute_type="float16": asr_core.py:141, api/config.py:12, faster_whisper_asr.py:95).
+    Gate for the engine's TTASR_COMPUTE_F16 mode."""
+    _golden_lowp(torch.float16, "tiny_f16.npz", "tiny f16")
+
+
+def _golden_lowp(dtype, fname, label):
     """Golden set G5: the SAME tiny-geometry model with every parameter cast to bfloat16 and HF's
     own bf16 arithmetic (residual stream, LayerNorm and logits all in bf16) - the precision regime of the reference's
     GPU path (asr_core.py:141 float16; this build measures in bf16).  Stored per greedy step and clip: the token HF picks,
     and the top-2 margin of the PROCESSED scores, so a bf16 engine can be held to token equality wherever the reference
     itself is not within rounding distance of a tie."""
     dims = PRESETS["tiny"]
-    model, st = hf_model(dims, dtype=torch.bfloat16)
+    model, st = hf_model(dims, dtype=dtype)
     fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
     pcm = [synth.noise_clip(0), synth.tonal_clip(1), synth.noise_clip(2), synth.burst_clip(3)]
     mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
-    enc = model.model.encoder(torch.from_numpy(mel).to(torch.bfloat16)).last_hidden_state
+    enc = model.model.encoder(torch.from_numpy(mel).to(dtype)).last_hidden_state
     suppress = list(NON_SPEECH_TOKENS_MULTI) + [st.translate, st.transcribe, st.sot, st.sot_prev, st.no_speech]
     begin_suppress = [220, st.eot]
     out = dict(clips=np.array(["noise0", "tonal1", "noise2", "burst3"]), suppress=np.array(suppress),
@@ -272,8 +283,8 @@ def golden_bf16():
         out[f"{tag}_margin"] = np.stack(margins).astype(np.float32)
         out[f"{tag}_runner_up"] = np.stack(second)
         out[f"{tag}_logits_stride"] = raw[:, :, ::97]
-        print("tiny bf16", tag, toks.T.tolist()[0][:10], "min margin", float(np.stack(margins).min()))
-    np.savez_compressed(os.path.join(OUT, "tiny_bf16.npz"), **out)
+        print(label, tag, toks.T.tolist()[0][:10], "min margin", float(np.stack(margins).min()))
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def golden_beam():
@@ -310,10 +321,14 @@ def golden_beam():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--f16-only" in sys.argv:      # round 3: adds tests/golden/tiny_f16.npz without touching the older fixtures
+        golden_f16()
+        sys.exit(0)
     golden_mel()
     golden_rules()
     golden_micro()
     golden_tiny()
     golden_align()
     golden_bf16()
+    golden_f16()
     golden_beam()

@@ -136,14 +136,18 @@ class Dims:
     n_text_ctx: int = 448
 
 
-def to_torch(sd: Dict[str, np.ndarray], round_bf16: bool = False) -> Dict[str, torch.Tensor]:
-    """numpy state dict -> torch f32.  round_bf16 rounds every matrix the bf16 engine stores in bf16
-    (all >=2-D tensors) so the oracle sees the same weight values as the bf16 kernels."""
+def to_torch(sd: Dict[str, np.ndarray], round_bf16: bool = False, round_f16: bool = False) -> Dict[str, torch.Tensor]:
+    """numpy state dict -> torch f32.  round_bf16 / round_f16 round every matrix a 16-bit engine stores in that type
+    (all >=2-D tensors) so the oracle sees the same weight values as the 16-bit kernels.  The engine keeps the encoder's
+    sinusoid table in f32 in every mode; the f16 rounding leaves it alone (the bf16 rounding, pinned by round-1/2 tolerances,
+    still rounds it: the difference is far inside the bf16 tolerances)."""
     out = {}
     for k, v in sd.items():
         t = torch.from_numpy(np.ascontiguousarray(v)).float()
         if round_bf16 and t.dim() >= 2:
             t = t.bfloat16().float()
+        elif round_f16 and t.dim() >= 2 and k != "model.encoder.embed_positions.weight":
+            t = t.half().float()
         out[k] = t
     return out
 

@@ -19,6 +19,7 @@ N_FRAMES = N_SAMPLES // HOP  # 3000
 
 COMPUTE_F32 = 0
 COMPUTE_BF16 = 1
+COMPUTE_F16 = 2   # IEEE fp16 storage, f32 accumulate: what compute_type="float16" (asr_core.py:141, api/config.py:12) means
 
 
 @dataclass(frozen=True)

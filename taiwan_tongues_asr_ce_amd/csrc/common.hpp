@@ -19,12 +19,54 @@ __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
   typedef float f32x2_hw __attribute__((ext_vector_type(2)));
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){lo, hi}, bf16x2_hw));
 }
+// The second 16-bit storage format: IEEE fp16 (the reference's GPU arithmetic: compute_type="float16" at asr_core.py:141,
+// api/config.py:12, faster_whisper_asr.py:95).  Raw bits in a struct of its own so that templates can tell the two 16-bit
+// formats apart; every kernel that handles bf16_t also handles f16_t through N16<T> below - same tiles, same schedules, the
+// f16 forms of the MFMAs (same cycles as the bf16 forms), v_cvt_pk_f16_f32 / v_cvt_f32_f16 for the conversions.
+struct f16_t { uint16_t bits; };
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef _Float16 h16x2_hw __attribute__((ext_vector_type(2)));
+
+template <typename T> struct N16;   // number format of a 16-bit storage type: conversions + MFMA forms
+template <> struct N16<bf16_t> {
+  static __device__ __forceinline__ float up(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+  static __device__ __forceinline__ void up2(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ uint32_t pk(float lo, float hi) { return f2bf_pk(lo, hi); }
+  static __device__ __forceinline__ uint16_t down(float f) { return f2bf(f); }
+  static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct N16<f16_t> {
+  static __device__ __forceinline__ float up(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ void up2(uint32_t w, float& lo, float& hi) {
+    const h16x2_hw v = __builtin_bit_cast(h16x2_hw, w);
+    lo = (float)v[0]; hi = (float)v[1];
+  }
+  static __device__ __forceinline__ uint32_t pk(float lo, float hi) {   // round-to-nearest-even, one v_cvt_pk_f16_f32
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){lo, hi}, h16x2_hw));
+  }
+  static __device__ __forceinline__ uint16_t down(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+};
+// 8 stored values (one 16-byte chunk) -> f32
+template <typename T> __device__ __forceinline__ void up8(const uint4& t, float (&v)[8]) {
+  N16<T>::up2(t.x, v[0], v[1]); N16<T>::up2(t.y, v[2], v[3]); N16<T>::up2(t.z, v[4], v[5]); N16<T>::up2(t.w, v[6], v[7]);
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ float to_f<f16_t>(f16_t v) { return N16<f16_t>::up(v.bits); }
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float v) { return f16_t{N16<f16_t>::down(v)}; }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -121,11 +163,13 @@ struct GemmArgs {
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------------------
 template <typename T> void launch_gemm_basic(const GemmArgs& g, hipStream_t s);
-void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s);  // requires M%128==0? no: see kernels_gemm.hip
+// the tiled 16-bit GEMMs (names keep "bf16": the kernels were written for it; T16 = bf16_t or f16_t picks the MFMA form and
+// the output conversion, nothing else differs)
+template <typename T16> void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s);
 bool gemm_bf16_fast_ok(const GemmArgs& g);
-void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s);
+template <typename T16> void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s);
 bool gemm_bf16_v2_ok(const GemmArgs& g);
-void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s);
+template <typename T16> void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s);
 bool gemm_bf16_v3_ok(const GemmArgs& g);
 
 template <typename T>
@@ -163,9 +207,10 @@ struct SlabIn {
 };
 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
-void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s);
+template <typename T16> void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s);
 // ksplit > 1 (from gemm_skinny_ksplit): workgroup (nb, ks) writes its partial tile to slab[ks]; bias is the consumer's
-bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit = 1,
+template <typename T16>
+bool launch_gemm_skinny(const T16* Wsh, const T16* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit = 1,
                         float* slab = nullptr, int64_t slab_stride = 0);
 int gemm_skinny_ksplit(int B, int N, int K, int want);
 // mel
@@ -184,10 +229,10 @@ void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_f
 
 // encoder attention over fused qkv [B*T][3d] -> out [B*T][d]
 template <typename T> void launch_enc_attn_simple(const T* qkv, T* out, int B, int T_, int H, hipStream_t s);
-void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s);
+template <typename T16> void launch_enc_attn_flash_bf16(const T16* qkv, T16* out, int B, int T_, int H, hipStream_t s);
 // cross-attention of n_q consecutive rows per clip against that clip's cross-KV cache, as one MFMA flash pass (prefill)
-void launch_cross_attn_flash_bf16(const bf16_t* q, const bf16_t* K, const bf16_t* V, bf16_t* out, int n_clips, int n_q, int H, int Tk,
-                                  hipStream_t s);
+template <typename T16>
+void launch_cross_attn_flash_bf16(const T16* q, const T16* K, const T16* V, T16* out, int n_clips, int n_q, int H, int Tk, hipStream_t s);
 
 // decoder
 // The rule scalars that change from one 30-s window to the next (prompt geometry with condition_on_previous_text, the token
@@ -253,6 +298,7 @@ void launch_beam_topk(const float* logits, BeamRowState st, RuleParams rp, int R
 void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows /*nullable*/, hipStream_t s,
                    int32_t* ticket, int total_rows);
 void launch_advance(int32_t* step, hipStream_t s);
-void launch_prep_weight(const void* src, int src_bf16, float* dst, int64_t n, int64_t conv_in, float scale, hipStream_t s);
+void launch_prep_weight(const void* src, int src_type /*0 f32, 1 bf16 bits, 2 fp16 bits*/, float* dst, int64_t n, int64_t conv_in, float scale,
+                        hipStream_t s);
 template <typename T> void launch_cast(const float* in, T* out, int64_t n, hipStream_t s);
 template <typename T> void launch_uncast(const T* in, float* out, int64_t n, hipStream_t s);

@@ -48,7 +48,8 @@ struct ttasr_ctx {
   hipStream_t stream = nullptr;
   hipStream_t cur = nullptr;      // stream the schedule helpers enqueue on
   std::string err;
-  bool bf16 = false;
+  bool lowp = false;   // 16-bit storage mode (bf16 or fp16 weights / activations, f32 accumulate / LayerNorm / softmax)
+  bool f16 = false;    // ... and the 16-bit format is IEEE fp16 (TTASR_COMPUTE_F16) instead of bf16
   bool finalized = false;
   bool force_basic = false;
   bool use_graph = true;
@@ -180,6 +181,13 @@ int dalloc(ttasr_ctx* c, P** p, size_t bytes, bool zero = true) {
   return 0;
 }
 #define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
+// Run CALL with T = the context's storage type (float | bf16_t | f16_t)
+#define TT_DISPATCH(c_, CALL)                                   \
+  do {                                                          \
+    if (!(c_)->lowp) { using T = float; CALL; }                 \
+    else if ((c_)->f16) { using T = f16_t; CALL; }              \
+    else { using T = bf16_t; CALL; }                            \
+  } while (0)
 
 // slaney mel filter bank, same construction as the oracle's mel_filter_bank (float64, cast to f32)
 double hz2mel(double f) {
@@ -286,7 +294,7 @@ int build_weights(ttasr_ctx* c) {
     TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
   }
   TRY(ln("model.decoder.layer_norm", &c->dlnf_g, &c->dlnf_b));
-  if (c->bf16) {  // fragment-packed copies of every matrix the decode step streams
+  if (c->lowp) {  // fragment-packed copies of every matrix the decode step streams
     auto packed = [&](const std::string& name, void** base, int64_t rows_total, int64_t K, int row_off) -> int {
       if (!*base) TRY(alloc_mat(c, base, (rows_total + 31) / 32 * 32 * K));
       Slot& s = c->slots[name];
@@ -392,9 +400,9 @@ void gemm(ttasr_ctx* c, const GemmArgs& g) {
       // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
       const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
-      if ((v ? v == 3 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3(g, c->cur); return; }
-      if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2(g, c->cur); return; }
-      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast(g, c->cur); return; }
+      if ((v ? v == 3 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3<T>(g, c->cur); return; }
+      if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2<T>(g, c->cur); return; }
+      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast<T>(g, c->cur); return; }
     }
   }
   launch_gemm_basic<T>(g, c->cur);
@@ -405,7 +413,7 @@ template <typename T>
 void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
   if (c->skip_mask & 2) return;
   if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
+    if (!c->force_basic && Wsh && launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
   }
   launch_gemm_basic<T>(g, c->cur);
 }
@@ -488,10 +496,11 @@ int run_encoder(ttasr_ctx* c, int B) {
     ln(L.ln1g, L.ln1b, c->h);
     { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
     enc_mark(c, EC_QKV);
-    if (sizeof(T) == 2 && !c->force_basic && !c->no_flash)
-      launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, T_, c->H, s);
-    else
-      launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
+    bool flash = false;
+    if constexpr (sizeof(T) == 2) {
+      if (!c->force_basic && !c->no_flash) { launch_enc_attn_flash_bf16<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s); flash = true; }
+    }
+    if (!flash) launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
     enc_mark(c, EC_ATTN);
     residual_gemm(c->att, L.wo, L.bo, d, EC_OUT);
     ln(L.ln2g, L.ln2b, c->h);
@@ -550,7 +559,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
         GemmEpi ep; ep.ldc = g.N;
         float* slab = slab_base;  // rows are local to this chain's region: [ks][maxB][N]
         const int64_t stride = (int64_t)c->maxB * g.N;
-        if (launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, n, g.N, g.K, ep, s, ks, slab, stride)) {
+        if (launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, n, g.N, g.K, ep, s, ks, slab, stride)) {
           si.slab = slab; si.bias = bias; si.n = ks; si.stride = stride; si.ld = g.N;
         }
       }
@@ -640,7 +649,7 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
   const bool small = n <= 128 && !c->force_basic && !c->prefill_tiled;
   auto pgemm = [&](const GemmArgs& g, const void* Wsh) {
     if constexpr (sizeof(T) == 2) {
-      if (small && Wsh && launch_gemm_skinny((const bf16_t*)Wsh, (const bf16_t*)g.A, g.M, g.N, g.K, g.epi, s)) return;
+      if (small && Wsh && launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, s)) return;
     }
     gemm<T>(c, g);
   };
@@ -711,7 +720,7 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
 
 int step_graph(ttasr_ctx* c, int B, int mode) {
   if (!c->use_graph) {
-    if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
+    TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
     return 0;
   }
   const int variant = c->kv_div * 2 + c->identity_pages;
@@ -719,7 +728,7 @@ int step_graph(ttasr_ctx* c, int B, int mode) {
     if (g.B == B && g.mode == mode && g.variant == variant) { HIPCHK(c, hipGraphLaunch(g.exec, c->stream)); return 0; }
   hipGraph_t graph;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  if (c->bf16) run_decode_step<bf16_t>(c, B, mode); else run_decode_step<float>(c, B, mode);
+  TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
   HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
   hipGraphExec_t exec;
   HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -876,8 +885,8 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (cfg->n_mels % 8 || cfg->n_mels <= 0 || cfg->ffn_dim % 64 || cfg->n_audio_ctx < 1 || cfg->vocab < 2 ||
       cfg->n_text_ctx < 2 || cfg->n_text_ctx > 448 || cfg->enc_layers < 1 || cfg->dec_layers < 1 || cfg->max_batch < 1)
     return fail(nullptr, TTASR_E_INVALID, "unsupported geometry");
-  if (cfg->compute_type != TTASR_COMPUTE_F32 && cfg->compute_type != TTASR_COMPUTE_BF16)
-    return fail(nullptr, TTASR_E_INVALID, "compute_type must be 0 (f32) or 1 (bf16)");
+  if (cfg->compute_type != TTASR_COMPUTE_F32 && cfg->compute_type != TTASR_COMPUTE_BF16 && cfg->compute_type != TTASR_COMPUTE_F16)
+    return fail(nullptr, TTASR_E_INVALID, "compute_type must be 0 (f32), 1 (bf16) or 2 (fp16)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -885,7 +894,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (device_id < 0 || device_id >= ndev) return fail(nullptr, TTASR_E_INVALID, "device %d of %d", device_id, ndev);
   std::unique_ptr<ttasr_ctx> c(new ttasr_ctx());
   c->cfg = *cfg; c->device = device_id;
-  c->bf16 = cfg->compute_type == TTASR_COMPUTE_BF16; c->esz = c->bf16 ? 2 : 4;
+  c->lowp = cfg->compute_type != TTASR_COMPUTE_F32; c->f16 = cfg->compute_type == TTASR_COMPUTE_F16; c->esz = c->lowp ? 2 : 4;
   c->T = cfg->n_audio_ctx; c->F = 2 * c->T; c->d = cfg->d_model; c->H = cfg->n_heads; c->ffn = cfg->ffn_dim;
   c->V = cfg->vocab; c->ldv = (cfg->vocab + 63) / 64 * 64; c->M = cfg->n_mels; c->maxB = cfg->max_batch;
   c->n_samples = c->F * 160;
@@ -960,7 +969,7 @@ void ttasr_destroy(ttasr_ctx* c) {
 // Shared by the host and device entry points: `src` is a DEVICE pointer to the tensor in its source layout (float32 or
 // bf16 bits); everything from here on - conv tap re-ordering, q pre-scaling, bf16 cast, MFMA-fragment packing - runs on
 // the device.
-static int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int src_bf16, const int64_t* dims, int32_t ndim) {
+static int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int src_type, const int64_t* dims, int32_t ndim) {
   if (std::string(name) == "proj_out.weight") return TTASR_OK;  // tied to embed_tokens
   auto it = c->slots.find(name);
   if (it == c->slots.end()) return fail(c, TTASR_E_WEIGHTS, "unknown tensor '%s'", name);
@@ -974,13 +983,18 @@ static int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int sr
     if (ndim != 3 || dims[2] != 3) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': expected [out][in][3]", name);
     conv_in = dims[1];
   }
-  const bool to_f32 = s.kind == 1 || s.kind == 3 || !c->bf16;
+  const bool to_f32 = s.kind == 1 || s.kind == 3 || !c->lowp;
   if (!to_f32 && (size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
   float* f32_dst = to_f32 ? (float*)s.dst : c->stage_f32;
-  launch_prep_weight(src, src_bf16, f32_dst, n, conv_in, s.scale, c->stream);
+  launch_prep_weight(src, src_type, f32_dst, n, conv_in, s.scale, c->stream);
   if (!to_f32) {
-    launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
-    if (s.sh_base) launch_shuffle_cast(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
+    if (c->f16) {
+      launch_cast<f16_t>(c->stage_f32, (f16_t*)s.dst, n, c->stream);
+      if (s.sh_base) launch_shuffle_cast<f16_t>(c->stage_f32, (f16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
+    } else {
+      launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
+      if (s.sh_base) launch_shuffle_cast<bf16_t>(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
+    }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffers are reused by the next tensor
   HIPCHK(c, hipGetLastError());
@@ -1005,9 +1019,10 @@ int ttasr_load_tensor_device(ttasr_ctx* c, const char* name, const void* data_de
   return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
   if (!name || !data_dev || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
-  if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16) return fail(c, TTASR_E_INVALID, "dtype must be 0 (float32) or 1 (bfloat16 bits)");
+  if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16 && dtype != TTASR_DTYPE_F16)
+    return fail(c, TTASR_E_INVALID, "dtype must be 0 (float32), 1 (bfloat16 bits) or 2 (float16 bits)");
   HIPCHK(c, hipSetDevice(c->device));
-  return ingest_tensor(c, name, data_dev, dtype == TTASR_DTYPE_BF16, dims, ndim);
+  return ingest_tensor(c, name, data_dev, dtype, dims, ndim);
   });
 }
 
@@ -1045,8 +1060,7 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
   }
   HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
   launch_mel(src, stride, c->nsamp_dev, B, c->M, c->F, c->filters, c->dcos, c->dsin, c->window, c->mel, c->clip_max, s);
-  if (c->bf16) launch_mel_finish<bf16_t>(c->mel, c->clip_max, (bf16_t*)c->mel_t, B, c->M, c->F, s);
-  else launch_mel_finish<float>(c->mel, c->clip_max, (float*)c->mel_t, B, c->M, c->F, s);
+  TT_DISPATCH(c, launch_mel_finish<T>(c->mel, c->clip_max, (T*)c->mel_t, B, c->M, c->F, s));
   hipEventRecord(c->ev[1], s);
   if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
@@ -1097,8 +1111,7 @@ int ttasr_log_mel_windows(ttasr_ctx* c, const float* const* file_pcm_of, const i
     for (int b = 0; b < B; ++b) mx[b] = mel_max_to_ordered(floor_max[b]);
     HIPCHK(c, hipMemcpyAsync(c->clip_max, mx.data(), B * 4, hipMemcpyHostToDevice, s));
   }
-  if (c->bf16) launch_mel_finish<bf16_t>(c->mel, c->clip_max, (bf16_t*)c->mel_t, B, c->M, c->F, s, c->mel_geom);
-  else launch_mel_finish<float>(c->mel, c->clip_max, (float*)c->mel_t, B, c->M, c->F, s, c->mel_geom);
+  TT_DISPATCH(c, launch_mel_finish<T>(c->mel, c->clip_max, (T*)c->mel_t, B, c->M, c->F, s, c->mel_geom));
   hipEventRecord(c->ev[1], s);
   if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));  // mx / ns / geom are stack temporaries
@@ -1115,8 +1128,7 @@ int ttasr_set_mel(ttasr_ctx* c, const float* mel, int32_t B) {
   if (B < 1 || B > c->maxB || !mel) return fail(c, TTASR_E_INVALID, "bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->mel, mel, (size_t)B * c->M * c->F * 4, hipMemcpyHostToDevice, c->stream));
-  if (c->bf16) launch_mel_transpose<bf16_t>(c->mel, (bf16_t*)c->mel_t, B, c->M, c->F, c->stream);
-  else launch_mel_transpose<float>(c->mel, (float*)c->mel_t, B, c->M, c->F, c->stream);
+  TT_DISPATCH(c, launch_mel_transpose<T>(c->mel, (T*)c->mel_t, B, c->M, c->F, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->B_mel = B;
@@ -1128,10 +1140,10 @@ int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
   return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (c->B_mel < B) return fail(c, TTASR_E_INVALID, "mel for %d clips requested but only %d resident", B, c->B_mel);
-  if (c->bf16) run_encoder<bf16_t>(c, B); else run_encoder<float>(c, B);
+  TT_DISPATCH(c, run_encoder<T>(c, B));
   if (out_enc) {
     const int64_t n = (int64_t)B * c->T * c->d;
-    if (c->bf16) { launch_uncast<bf16_t>((const bf16_t*)c->enc_out, c->x, n, c->stream);
+    if (c->lowp) { TT_DISPATCH(c, launch_uncast<T>((const T*)c->enc_out, c->x, n, c->stream));
                    HIPCHK(c, hipMemcpyAsync(out_enc, c->x, n * 4, hipMemcpyDeviceToHost, c->stream)); }
     else HIPCHK(c, hipMemcpyAsync(out_enc, c->enc_out, n * 4, hipMemcpyDeviceToHost, c->stream));
   }
@@ -1166,10 +1178,10 @@ int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
   TRY(check_ready(c, B));
   if (!enc) return fail(c, TTASR_E_INVALID, "enc is NULL");
   const int64_t n = (int64_t)B * c->T * c->d;
-  if (c->bf16) { HIPCHK(c, hipMemcpyAsync(c->x, enc, n * 4, hipMemcpyHostToDevice, c->stream));
-                 launch_cast<bf16_t>(c->x, (bf16_t*)c->enc_out, n, c->stream); }
+  if (c->lowp) { HIPCHK(c, hipMemcpyAsync(c->x, enc, n * 4, hipMemcpyHostToDevice, c->stream));
+                 TT_DISPATCH(c, launch_cast<T>(c->x, (T*)c->enc_out, n, c->stream)); }
   else HIPCHK(c, hipMemcpyAsync(c->enc_out, enc, n * 4, hipMemcpyHostToDevice, c->stream));
-  if (c->bf16) run_cross_kv<bf16_t>(c, B); else run_cross_kv<float>(c, B);
+  TT_DISPATCH(c, run_cross_kv<T>(c, B));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->B_enc = B;
@@ -1184,7 +1196,7 @@ int ttasr_get_cross_kv(ttasr_ctx* c, int32_t layer, int32_t which, int32_t B, fl
     return fail(c, TTASR_E_INVALID, "bad arguments");
   const int64_t n = (int64_t)B * c->H * c->T * 64;
   const char* src = (const char*)c->xkv + ((size_t)layer * c->xkv_layer_elems + (size_t)which * c->xkv_which_elems) * c->esz;
-  if (c->bf16) { launch_uncast<bf16_t>((const bf16_t*)src, c->x, n, c->stream);
+  if (c->lowp) { TT_DISPATCH(c, launch_uncast<T>((const T*)src, c->x, n, c->stream));
                  HIPCHK(c, hipMemcpyAsync(out, c->x, n * 4, hipMemcpyDeviceToHost, c->stream)); }
   else HIPCHK(c, hipMemcpyAsync(out, src, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1272,10 +1284,9 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   // <|startoftranscript|> position is only folded into the prefill when the prompt is long (previous-text prompts)
   const int pre = prefill_positions(c, min_plen, o, /*ns_from_prefill=*/min_plen - 1 >= c->prefill_ns_min);
   if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
-    if (c->bf16) run_prefill<bf16_t>(c, R, pre, rows_per_clip, max_prompt); else run_prefill<float>(c, R, pre, rows_per_clip, max_prompt);
+    TT_DISPATCH(c, run_prefill<T>(c, R, pre, rows_per_clip, max_prompt));
     if (o->no_speech >= 0 && o->sot_index < pre) {  // the <|startoftranscript|> position was prefilled: its logits come from here
-      if (c->bf16) TRY(prefill_no_speech<bf16_t>(c, R, pre, o->sot_index, o->no_speech));
-      else TRY(prefill_no_speech<float>(c, R, pre, o->sot_index, o->no_speech));
+      TT_DISPATCH(c, TRY(prefill_no_speech<T>(c, R, pre, o->sot_index, o->no_speech)));
     }
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
@@ -1415,7 +1426,7 @@ static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t
     HIPCHK(c, hipMemcpyAsync(c->page_table, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * max_prompt * 4, hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));  // ptab is a stack temporary
-    if (c->bf16) run_prefill<bf16_t>(c, A, pre, 1, max_prompt); else run_prefill<float>(c, A, pre, 1, max_prompt);
+    TT_DISPATCH(c, run_prefill<T>(c, A, pre, 1, max_prompt));
     c->pinned_i32[1] = pre;
     HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
     rebuild_free(n_pg - 1);
@@ -1440,8 +1451,7 @@ static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t
     }
     if (!pairs.empty()) {
       HIPCHK(c, hipMemcpyAsync(c->pairs_dev, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
-      if (c->bf16) launch_copy_pages<bf16_t>((bf16_t*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s);
-      else launch_copy_pages<float>((float*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s);
+      TT_DISPATCH(c, launch_copy_pages<T>((T*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s));
     }
     {  // page tables are stored [row][pps] with unused entries clamped to a valid page id
       std::vector<int32_t> up(tbl);
@@ -1665,21 +1675,17 @@ int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok
   HIPCHK(c, hipStreamSynchronize(s));  // sel is a stack temporary
   c->B_dec = 0;  // the pass reuses sequence 0's self-attention pages: any step-level decode state is gone
   AlignOut al{clip, sel_dev, probs};
-  if (c->bf16) run_prefill<bf16_t>(c, 1, n_tok, 1, n_tok, &al); else run_prefill<float>(c, 1, n_tok, 1, n_tok, &al);
+  TT_DISPATCH(c, run_prefill<T>(c, 1, n_tok, 1, n_tok, &al));
   if (out_logprob) {
     // raw log p(tokens[i + 1] | tokens[0..i]): final LayerNorm + vocabulary projection, max_batch rows at a time
     for (int r0 = 0; r0 < n_tok - 1; r0 += c->maxB) {
       const int n = std::min(c->maxB, n_tok - 1 - r0);
       c->cur = s;
-      if (c->bf16) {
-        launch_layernorm<bf16_t>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (bf16_t*)c->dh, n, c->d, s);
-        GemmArgs g = lin_args<bf16_t>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-        dec_gemm<bf16_t>(c, g, c->emb_sh);
-      } else {
-        launch_layernorm<float>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (float*)c->dh, n, c->d, s);
-        GemmArgs g = lin_args<float>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-        dec_gemm<float>(c, g, nullptr);
-      }
+      TT_DISPATCH(c, {
+        launch_layernorm<T>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (T*)c->dh, n, c->d, s);
+        GemmArgs g = lin_args<T>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
+        dec_gemm<T>(c, g, c->emb_sh);
+      });
       launch_token_logprob(c->logits, c->ldv, c->V, c->prompt_dev + r0 + 1, lp_dev + r0, n, s);
     }
     HIPCHK(c, hipMemcpyAsync(out_logprob, lp_dev, (size_t)(n_tok - 1) * 4, hipMemcpyDeviceToHost, s));
@@ -1761,10 +1767,8 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       constexpr bool same_layer = false;
 #endif
       const char* Kx = (const char*)c->xkv + (size_t)(same_layer ? 0 : layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
-      if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
-                                                    (bf16_t*)c->datt, B, c->H, c->T, 1, s);
-      else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
-                                           (float*)c->datt, B, c->H, c->T, 1, s);
+      TT_DISPATCH(c, launch_cross_attn_decode<T>((const T*)c->dq, (const T*)Kx, (const T*)Kx + c->xkv_which_elems, (T*)c->datt, B, c->H,
+                                                 c->T, 1, s));
       bytes = (double)B * (2.0 * T_ * d + 2.0 * d) * e; flops = (double)B * 4.0 * T_ * d;
     } else if (k == "xattn_beam5" || k == "xattn_beam5_rows") {
       // B rows = B / 5 clips x 5 hypotheses sharing their clip's cross-KV: one stream per clip ("xattn_beam5") or the
@@ -1773,50 +1777,51 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       static int layer_rr2 = 0;
       const char* Kx = (const char*)c->xkv + (size_t)(layer_rr2++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
       float* ws = k == "xattn_beam5" ? c->xsplit_ws : nullptr;
-      if (c->bf16) launch_cross_attn_decode<bf16_t>((const bf16_t*)c->dq, (const bf16_t*)Kx, (const bf16_t*)Kx + c->xkv_which_elems,
-                                                    (bf16_t*)c->datt, B, c->H, c->T, 5, s, ws, SlabIn{}, c->maxB);
-      else launch_cross_attn_decode<float>((const float*)c->dq, (const float*)Kx, (const float*)Kx + c->xkv_which_elems,
-                                           (float*)c->datt, B, c->H, c->T, 5, s, ws, SlabIn{}, c->maxB);
+      TT_DISPATCH(c, launch_cross_attn_decode<T>((const T*)c->dq, (const T*)Kx, (const T*)Kx + c->xkv_which_elems, (T*)c->datt, B, c->H,
+                                                 c->T, 5, s, ws, SlabIn{}, c->maxB));
       bytes = (double)(B / 5) * 2.0 * T_ * d * e + (double)B * 2.0 * d * e; flops = (double)B * 4.0 * T_ * d;
     } else if (k == "enc_gemm_fc1") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].w1; g.M = B * c->T; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->enc[0].b1; g.epi.act = 1; g.epi.out_t = c->mid;
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      TT_DISPATCH(c, gemm<T>(c, g));
       bytes = ((double)B * T_ * (d + ffn) + ffn * d) * e; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_gemm_qkv") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].wqkv; g.M = B * c->T; g.N = 3 * c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = 3 * c->d; g.epi.bias = c->enc[0].bqkv; g.epi.out_t = c->qkv;
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      TT_DISPATCH(c, gemm<T>(c, g));
       bytes = ((double)B * T_ * 4 * d + 3 * d * d) * e; flops = 2.0 * B * T_ * d * 3 * d;
     } else if (k == "enc_gemm_out") {
       GemmArgs g; g.A = c->att; g.W = c->enc[0].wo; g.M = B * c->T; g.N = c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->d; g.epi.bias = c->enc[0].bo;
-      const bool delta = c->bf16 && !c->force_basic && !c->enc_res_epilogue;  // the epilogue run_encoder uses
+      const bool delta = c->lowp && !c->force_basic && !c->enc_res_epilogue;  // the epilogue run_encoder uses
       if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      TT_DISPATCH(c, gemm<T>(c, g));
       bytes = ((double)B * T_ * d + d * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * d;
     } else if (k == "enc_gemm_fc2") {
       GemmArgs g; g.A = c->mid; g.W = c->enc[0].w2; g.M = B * c->T; g.N = c->d; g.K = c->ffn; g.lda = c->ffn; g.ldw = c->ffn;
       g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2;
-      const bool delta = c->bf16 && !c->force_basic && !c->enc_res_epilogue;
+      const bool delta = c->lowp && !c->force_basic && !c->enc_res_epilogue;
       if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
-      if (c->bf16) gemm<bf16_t>(c, g); else gemm<float>(c, g);
+      TT_DISPATCH(c, gemm<T>(c, g));
       bytes = ((double)B * T_ * ffn + ffn * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
-      if (c->bf16) {
-        if (!c->force_basic && !c->no_flash) launch_enc_attn_flash_bf16((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
-        else launch_enc_attn_simple<bf16_t>((const bf16_t*)c->qkv, (bf16_t*)c->att, B, c->T, c->H, s);
-      } else launch_enc_attn_simple<float>((const float*)c->qkv, (float*)c->att, B, c->T, c->H, s);
+      TT_DISPATCH(c, {
+        bool flash = false;
+        if constexpr (sizeof(T) == 2) {
+          if (!c->force_basic && !c->no_flash) { launch_enc_attn_flash_bf16<T>((const T*)c->qkv, (T*)c->att, B, c->T, c->H, s); flash = true; }
+        }
+        if (!flash) launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, c->T, c->H, s);
+      });
       bytes = (double)B * T_ * 4.0 * d * e; flops = 4.0 * B * T_ * T_ * d;
     } else if (k == "dec_gemm_fc1") {
       GemmArgs g; g.A = c->dh; g.W = c->dec[0].w1; g.M = B; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->dec[0].b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      if (c->bf16) dec_gemm<bf16_t>(c, g, c->dec[0].w1_sh); else dec_gemm<float>(c, g, nullptr);
+      TT_DISPATCH(c, dec_gemm<T>(c, g, c->lowp ? c->dec[0].w1_sh : nullptr));
       bytes = (ffn * d + (double)B * (d + ffn)) * e; flops = 2.0 * B * d * ffn;
     } else if (k == "logits_gemm") {
       GemmArgs g; g.A = c->dh; g.W = c->emb; g.M = B; g.N = c->V; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ldv; g.epi.out_f32 = c->logits;
-      if (c->bf16) dec_gemm<bf16_t>(c, g, c->emb_sh); else dec_gemm<float>(c, g, nullptr);
+      TT_DISPATCH(c, dec_gemm<T>(c, g, c->lowp ? c->emb_sh : nullptr));
       bytes = (double)c->V * d * e + (double)B * c->V * 4.0; flops = 2.0 * B * d * c->V;
     } else {
       return fail(c, TTASR_E_INVALID, "unknown kernel '%s'", name);

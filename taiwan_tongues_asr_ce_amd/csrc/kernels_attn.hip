@@ -76,6 +76,7 @@ void launch_enc_attn_simple(const T* qkv, T* out, int B, int Tn, int H, hipStrea
 }
 template void launch_enc_attn_simple<float>(const float*, float*, int, int, int, hipStream_t);
 template void launch_enc_attn_simple<bf16_t>(const bf16_t*, bf16_t*, int, int, int, hipStream_t);
+template void launch_enc_attn_simple<f16_t>(const f16_t*, f16_t*, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // helpers: one 16-byte chunk of a K/V row per lane.  VEC elements, LPR lanes per 64-element row.
@@ -88,16 +89,15 @@ template <> struct RowVec<float> {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
 };
-template <> struct RowVec<bf16_t> {
+template <typename T16> struct RowVec16 {
   static constexpr int VEC = 8;
-  __device__ static void load(const bf16_t* p, float (&v)[8]) {
-    uint4 t = *(const uint4*)p;
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  __device__ static void load(const T16* p, float (&v)[8]) {
+    const uint4 t = *(const uint4*)p;
+    up8<T16>(t, v);
   }
 };
+template <> struct RowVec<bf16_t> : RowVec16<bf16_t> {};
+template <> struct RowVec<f16_t> : RowVec16<f16_t> {};
 
 // One 16-byte chunk of a query / key / value row from the K-split partial tiles of the decode GEMM that produced it:
 // v = round_T(bias + slab[0] + ... + slab[n-1]) in slab order (bit-reproducible), i.e. exactly what the unsplit GEMM's
@@ -136,6 +136,12 @@ template <> __device__ __forceinline__ void store_row<bf16_t>(bf16_t* p, const f
   o.y = (__float_as_uint(v[2]) >> 16) | (__float_as_uint(v[3]) & 0xffff0000u);
   o.z = (__float_as_uint(v[4]) >> 16) | (__float_as_uint(v[5]) & 0xffff0000u);
   o.w = (__float_as_uint(v[6]) >> 16) | (__float_as_uint(v[7]) & 0xffff0000u);
+  *(uint4*)p = o;
+}
+template <> __device__ __forceinline__ void store_row<f16_t>(f16_t* p, const float (&v)[8]) {
+  uint4 o;  // v holds exactly representable fp16 values: the conversion is exact
+  o.x = N16<f16_t>::pk(v[0], v[1]); o.y = N16<f16_t>::pk(v[2], v[3]);
+  o.z = N16<f16_t>::pk(v[4], v[5]); o.w = N16<f16_t>::pk(v[6], v[7]);
   *(uint4*)p = o;
 }
 
@@ -309,6 +315,8 @@ void launch_self_attn_prefill(const T* qkv, T* kv_pool, const int32_t* page_tabl
 template void launch_self_attn_prefill<float>(const float*, float*, const int32_t*, int, int64_t, int, float*, int, int, int, hipStream_t);
 template void launch_self_attn_prefill<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, bf16_t*, int, int, int,
                                                hipStream_t);
+template void launch_self_attn_prefill<f16_t>(const f16_t*, f16_t*, const int32_t*, int, int64_t, int, f16_t*, int, int, int,
+                                               hipStream_t);
 
 // copy-on-write of partially filled KV pages after a beam re-index: pairs (src, dst) x all layers
 template <typename T>
@@ -327,10 +335,13 @@ void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_lay
 }
 template void launch_copy_pages<float>(float*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_copy_pages<bf16_t>(bf16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
+template void launch_copy_pages<f16_t>(f16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, int, const int32_t*, float*,
                                              int, int, hipStream_t, SlabIn);
 template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
                                               bf16_t*, int, int, hipStream_t, SlabIn);
+template void launch_self_attn_decode<f16_t>(const f16_t*, f16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
+                                              f16_t*, int, int, hipStream_t, SlabIn);
 
 // ------------------------------------------------------------------------------------------------
 // decoder cross-attention.  K, V: [B][H][Tk][64] (head-major, written by the cross-KV GEMM epilogue), so
@@ -348,10 +359,7 @@ template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int3
 template <typename T, bool NT> __device__ __forceinline__ void load_row(const T* p, float (&v)[RowVec<T>::VEC]) {
   if constexpr (NT && sizeof(T) == 2) {
     const u32x4_t t = __builtin_nontemporal_load((const u32x4_t*)p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    up8<T>(make_uint4(t.x, t.y, t.z, t.w), v);
   } else {
     RowVec<T>::load(p, v);
   }
@@ -752,7 +760,7 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
   // the clip's frames (kernels_flash.hip, CROSS) - K and V are streamed once per (clip, head, 128 rows)
   if constexpr (sizeof(T) == 2) {
     if (split_ws && kv_div >= 32 && B % kv_div == 0 && sq.n == 0) {
-      launch_cross_attn_flash_bf16((const bf16_t*)q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, B / kv_div, kv_div, H, Tk, s);
+      launch_cross_attn_flash_bf16<T>(q, K, V, out, B / kv_div, kv_div, H, Tk, s);
       return;
     }
   }
@@ -814,7 +822,11 @@ template void launch_cross_attn_probs<float>(const float*, const float*, const f
                                              hipStream_t);
 template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, const int*, float*,
                                               hipStream_t);
+template void launch_cross_attn_probs<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, const int*, float*,
+                                              hipStream_t);
 template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*,
                                               SlabIn, int);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
+                                               float*, SlabIn, int);
+template void launch_cross_attn_decode<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, int, hipStream_t,
                                                float*, SlabIn, int);

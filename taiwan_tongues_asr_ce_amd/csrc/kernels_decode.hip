@@ -24,6 +24,7 @@ void launch_embed_prefill(const int32_t* prompt, int max_prompt, int rows_per_pr
 }
 template void launch_embed_prefill<float>(const int32_t*, int, int, int, int, const float*, const float*, float*, int, hipStream_t);
 template void launch_embed_prefill<bf16_t>(const int32_t*, int, int, int, int, const bf16_t*, const bf16_t*, float*, int, hipStream_t);
+template void launch_embed_prefill<f16_t>(const int32_t*, int, int, int, int, const f16_t*, const f16_t*, float*, int, hipStream_t);
 
 __global__ void advance_kernel(int32_t* step) { *step += 1; }
 void launch_advance(int32_t* step, hipStream_t s) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, step); }

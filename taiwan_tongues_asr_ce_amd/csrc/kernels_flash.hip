@@ -33,7 +33,7 @@ constexpr int FA_QB = 128, FA_KB = 64;
 // CROSS = false: encoder self-attention, q / k / v rows interleaved in one [B][Tn][3d] tensor (n_k == Tn).
 // CROSS = true: the decoder's cross-attention for MANY query rows per clip (a prompt prefill pass): q = [clip][Tn][d] rows, K / V
 // from the cross-KV cache [clip][head][n_k][64] - the clip's frames are streamed once for all of its prompt positions.
-template <bool CROSS>
+template <typename T16, bool CROSS>
 __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
                                                              int H, const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx,
                                                              int n_k_cross) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s16x8 kf = *(const s16x8*)(Kb + krow * 128 + (((2 * ks + hf) ^ ksw) << 4));
-        s[kb2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb2], 0, 0, 0);
+        s[kb2] = N16<T16>::mfma32(kf, qf[ks], s[kb2]);
       }
     }
     if (LAST) {  // mask keys past the end of the sequence (only the peeled last tile carries this code)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
         float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb2][j], LOG2E, mb));
         float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb2][j + 1], LOG2E, mb));
         psum += p0 + p1;
-        pf[kb2][j >> 1] = pack_bf16(p0, p1);
+        pf[kb2][j >> 1] = N16<T16>::pk(p0, p1);
       }
     // rescale the running sums only when some query of this wave saw a new maximum (exact: alpha == 1 otherwise);
     // after the first few tiles this is rare, and it keeps 32 multiplies + an exp out of the steady-state loop
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
           hi = lds_tr16(Vb + row1 * 128 + (((db ^ ((row1 >> 1) & 1)) << 6) | (vg << 5) | (vp4 << 3)));
         }
         s16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
+        o[db] = N16<T16>::mfma32(vf, pb, o[db]);
       }
     }
     if (!LAST) FA_S_STORE(cur ^ 1);
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       uint2 pk;
-      pk.x = pack_bf16(o[db][4 * rg + 0] * inv, o[db][4 * rg + 1] * inv);
-      pk.y = pack_bf16(o[db][4 * rg + 2] * inv, o[db][4 * rg + 3] * inv);
+      pk.x = N16<T16>::pk(o[db][4 * rg + 0] * inv, o[db][4 * rg + 1] * inv);
+      pk.y = N16<T16>::pk(o[db][4 * rg + 2] * inv, o[db][4 * rg + 3] * inv);
       const int dcol = 32 * db + 8 * rg + 4 * hf;
       *(uint2*)(ob + r * 144 + dcol * 2) = pk;
     }
@@ -226,14 +226,20 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   }
 }
 
-void launch_enc_attn_flash_bf16(const bf16_t* qkv, bf16_t* out, int B, int T_, int H, hipStream_t s) {
+template <typename T16>
+void launch_enc_attn_flash_bf16(const T16* qkv, T16* out, int B, int T_, int H, hipStream_t s) {
   dim3 grid((T_ + FA_QB - 1) / FA_QB, H, B);
-  hipLaunchKernelGGL(enc_attn_flash_kernel<false>, grid, dim3(256), 32768, s, qkv, out, T_, H, (const bf16_t*)nullptr,
-                     (const bf16_t*)nullptr, 0);
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
+                     (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
 }
 // q = [n_clips][n_q][d] (the n_q rows of a clip are consecutive), K / V = cross-KV cache of those clips, out like q
-void launch_cross_attn_flash_bf16(const bf16_t* q, const bf16_t* K, const bf16_t* V, bf16_t* out, int n_clips, int n_q, int H, int Tk,
-                                  hipStream_t s) {
+template <typename T16>
+void launch_cross_attn_flash_bf16(const T16* q, const T16* K, const T16* V, T16* out, int n_clips, int n_q, int H, int Tk, hipStream_t s) {
   dim3 grid((n_q + FA_QB - 1) / FA_QB, H, n_clips);
-  hipLaunchKernelGGL(enc_attn_flash_kernel<true>, grid, dim3(256), 32768, s, q, out, n_q, H, K, V, Tk);
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, true>), grid, dim3(256), 32768, s, (const bf16_t*)q, (bf16_t*)out, n_q, H,
+                     (const bf16_t*)K, (const bf16_t*)V, Tk);
 }
+template void launch_enc_attn_flash_bf16<bf16_t>(const bf16_t*, bf16_t*, int, int, int, hipStream_t);
+template void launch_enc_attn_flash_bf16<f16_t>(const f16_t*, f16_t*, int, int, int, hipStream_t);
+template void launch_cross_attn_flash_bf16<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t);
+template void launch_cross_attn_flash_bf16<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, int, hipStream_t);

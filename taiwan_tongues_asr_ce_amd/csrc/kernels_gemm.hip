@@ -38,6 +38,7 @@ __device__ __forceinline__ void epi_store(const GemmEpi& e, int64_t zoff, int m,
 template <typename T> struct BasicCfg;
 template <> struct BasicCfg<float> { static constexpr int VEC = 4, PAD = 4; };
 template <> struct BasicCfg<bf16_t> { static constexpr int VEC = 8, PAD = 8; };
+template <> struct BasicCfg<f16_t> { static constexpr int VEC = 8, PAD = 8; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_basic_kernel(GemmArgs g) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_basic_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = N16<T>::mfma16(a[i], b[j], acc[i][j]);
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
@@ -117,6 +118,7 @@ void launch_gemm_basic(const GemmArgs& g, hipStream_t s) {
 }
 template void launch_gemm_basic<float>(const GemmArgs&, hipStream_t);
 template void launch_gemm_basic<bf16_t>(const GemmArgs&, hipStream_t);
+template void launch_gemm_basic<f16_t>(const GemmArgs&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // gemm_bf16_fast: 128x128x64, glds double buffer
@@ -131,6 +133,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
+template <typename T16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BM = 128, BN = 128, BK = 64;
   constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmArgs g, int 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(a[i], b[j], acc[i][j]);
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone finished reading `cur`
   }
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmArgs g, int 
       for (int rr = 0; rr < 4; ++rr) {
         int m = m0 + wm * 64 + i * 16 + fq * 4 + rr;
         int n = n0 + wn * 64 + j * 16 + fr;
-        if (m < g.M) epi_store<bf16_t>(g.epi, zoff, m, n, acc[i][j][rr]);
+        if (m < g.M) epi_store<T16>(g.epi, zoff, m, n, acc[i][j][rr]);
       }
 }
 
@@ -238,6 +241,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 // 4 consecutive columns n..n+3 of row m
+template <typename T16>
 __device__ __forceinline__ void epi_store4(const GemmEpi& e, int64_t zoff, int m, int n, f32x4 v) {
   if (e.bias) {
     const float4 b = *(const float4*)(e.bias + n);
@@ -264,15 +268,14 @@ __device__ __forceinline__ void epi_store4(const GemmEpi& e, int64_t zoff, int m
       const int b = m / e.hs_T, t = m - b * e.hs_T;
       idx = (int64_t)which * e.hs_which + (((int64_t)b * e.hs_H + h) * e.hs_T + t) * 64 + j;
     }
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
     uint2 pk;
-    pk.x = __builtin_bit_cast(uint32_t, lo);
-    pk.y = __builtin_bit_cast(uint32_t, hi);
+    pk.x = N16<T16>::pk(v[0], v[1]);
+    pk.y = N16<T16>::pk(v[2], v[3]);
     *(uint2*)((bf16_t*)e.out_t + idx) = pk;
   }
 }
 
+template <typename T16>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BM = 256, BN = 128, BK = 64;
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + W_BYTES;  // 32K + 16K
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][j], a[0][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = N16<T16>::mfma16(b[0][j], a[0][i], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]), "+v"(b[1][0]),
                  "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][j], a[1][i], acc[i][j], 0, 0, 0);
+        acc[i][j] = N16<T16>::mfma16(b[1][j], a[1][i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     cur = cur == 2 ? 0 : cur + 1;
   }
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(GemmArgs g, int ti
     const int m = m0 + wm * 64 + i * 16 + fr;
     if (m < g.M) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) epi_store4(g.epi, zoff, m, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
+      for (int j = 0; j < 4; ++j) epi_store4<T16>(g.epi, zoff, m, n0 + wn * 64 + j * 16 + fq * 4, acc[i][j]);
     }
   }
 }
@@ -393,17 +396,20 @@ bool gemm_bf16_v2_ok(const GemmArgs& g) {
   return g.N % 128 == 0 && g.K % 64 == 0 && g.K >= 128 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.epi.ldc % 4 == 0 &&
          ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 && (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
 }
+template <typename T16>
 void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
-  static bool attr_done[64] = {false};  // per device, see launch_v3
+  static bool attr_done[64] = {false};  // per device (and per instantiation), see launch_v3
   int dev = 0;
   hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+    hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<T16>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
     attr_done[dev & 63] = true;
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 128;
-  hipLaunchKernelGGL(gemm_bf16_v2_kernel, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 3 * 49152, s, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL(gemm_bf16_v2_kernel<T16>, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 3 * 49152, s, g, tiles_m, tiles_n);
 }
+template void launch_gemm_bf16_v2<bf16_t>(const GemmArgs&, hipStream_t);
+template void launch_gemm_bf16_v2<f16_t>(const GemmArgs&, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // gemm_bf16_v3: 256x256x32 stages, FOUR-stage LDS ring (128 KiB), 8 waves as 2 (M) x 4 (N), 128x64 per wave.
@@ -423,7 +429,7 @@ void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int v3_h(int q) { return (0x78 >> (q * 2)) & 3; }  // {0,2,3,1} packed two bits each
 
-template <int EPI>  // bit0 GELU, bit1 residual, bit2 row table (positions), bit3 head-split T output, bit4 f32 output
+template <typename T16, int EPI>  // EPI: bit0 GELU, bit1 residual, bit2 row table (positions), bit3 head-split T output, bit4 f32 output
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int tiles_m, int tiles_n) {
   constexpr int BM = 256, BN = 256, BK = 32;
   constexpr int OP_BYTES = BM * BK * 2, STAGE_BYTES = 2 * OP_BYTES;  // 16K + 16K
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)  // A operand = weight rows (n), B operand = activation rows (m)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -580,10 +586,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs g, int ti
         if (OUTF) {
           if (row_ok) *(float4*)(e.out_f32 + rowlin[ii] + nbase + j * 16) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-          bf2 lo = {(__bf16)v[0], (__bf16)v[1]}, hi = {(__bf16)v[2], (__bf16)v[3]};
-          pk[j].x = __builtin_bit_cast(uint32_t, lo);
-          pk[j].y = __builtin_bit_cast(uint32_t, hi);
+          pk[j].x = N16<T16>::pk(v[0], v[1]);
+          pk[j].y = N16<T16>::pk(v[2], v[3]);
         }
       }
       if (!OUTF) {
@@ -618,7 +622,7 @@ bool gemm_bf16_v3_ok(const GemmArgs& g) {
          g.epi.ldc % 8 == 0 && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0 &&
          (!g.epi.headsplit || g.epi.hs_d % 64 == 0);
 }
-template <int EPI>
+template <typename T16, int EPI>
 static void launch_v3(const GemmArgs& g, hipStream_t s) {
   // the opt-in to > 64 KB of dynamic LDS is per device: remember it per device (one process normally owns one GPU, but a
   // host that opens contexts on several must not launch on the second with the first one's flag)
@@ -626,30 +630,36 @@ static void launch_v3(const GemmArgs& g, hipStream_t s) {
   int dev = 0;
   hipGetDevice(&dev);
   if (!attr_done[dev & 63]) {
-    hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    hipFuncSetAttribute((const void*)gemm_bf16_v3_kernel<T16, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     attr_done[dev & 63] = true;
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
-  hipLaunchKernelGGL(gemm_bf16_v3_kernel<EPI>, dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL((gemm_bf16_v3_kernel<T16, EPI>), dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
 }
+template <typename T16>
 void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s) {
   switch (v3_epi_code(g.epi)) {
-    case 0: launch_v3<0>(g, s); break;    // bias -> T                 (qkv)
-    case 1: launch_v3<1>(g, s); break;    // bias + GELU -> T          (fc1, conv1)
-    case 18: launch_v3<18>(g, s); break;  // bias + residual -> f32    (out-proj, fc2)
-    case 21: launch_v3<21>(g, s); break;  // bias + GELU + positions -> f32 (conv2)
-    case 8: launch_v3<8>(g, s); break;    // bias -> head-split T      (cross-KV)
-    default: break;                       // excluded by gemm_bf16_v3_ok
+    case 0: launch_v3<T16, 0>(g, s); break;    // bias -> T                 (qkv)
+    case 1: launch_v3<T16, 1>(g, s); break;    // bias + GELU -> T          (fc1, conv1)
+    case 18: launch_v3<T16, 18>(g, s); break;  // bias + residual -> f32    (out-proj, fc2)
+    case 21: launch_v3<T16, 21>(g, s); break;  // bias + GELU + positions -> f32 (conv2)
+    case 8: launch_v3<T16, 8>(g, s); break;    // bias -> head-split T      (cross-KV)
+    default: break;                            // excluded by gemm_bf16_v3_ok
   }
 }
+template void launch_gemm_bf16_v3<bf16_t>(const GemmArgs&, hipStream_t);
+template void launch_gemm_bf16_v3<f16_t>(const GemmArgs&, hipStream_t);
 
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
   return g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.M >= 1 &&
          ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.W % 16) == 0;
 }
 
+template <typename T16>
 void launch_gemm_bf16_fast(const GemmArgs& g, hipStream_t s) {
   int tiles_m = (g.M + 127) / 128, tiles_n = g.N / 128;
   dim3 grid(tiles_m * tiles_n, 1, g.batch);
-  hipLaunchKernelGGL(gemm_bf16_fast_kernel, grid, dim3(256), 65536, s, g, tiles_m, tiles_n);
+  hipLaunchKernelGGL(gemm_bf16_fast_kernel<T16>, grid, dim3(256), 65536, s, g, tiles_m, tiles_n);
 }
+template void launch_gemm_bf16_fast<bf16_t>(const GemmArgs&, hipStream_t);
+template void launch_gemm_bf16_fast<f16_t>(const GemmArgs&, hipStream_t);

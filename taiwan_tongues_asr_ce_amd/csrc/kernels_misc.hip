@@ -152,8 +152,10 @@ void launch_mel_transpose(const float* mel, T* mel_t, int B, int n_mels, int n_f
 }
 template void launch_mel_finish<float>(float*, const unsigned*, float*, int, int, int, hipStream_t, const int64_t*);
 template void launch_mel_finish<bf16_t>(float*, const unsigned*, bf16_t*, int, int, int, hipStream_t, const int64_t*);
+template void launch_mel_finish<f16_t>(float*, const unsigned*, f16_t*, int, int, int, hipStream_t, const int64_t*);
 template void launch_mel_transpose<float>(const float*, float*, int, int, int, hipStream_t);
 template void launch_mel_transpose<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
+template void launch_mel_transpose<f16_t>(const float*, f16_t*, int, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (eps 1e-5), f32 residual stream in -> T out.  One wave per row; the row is read ONCE into
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
         dl[j] = ((const float4*)(delta + (int64_t)row * d))[i];
       } else {
         const uint2 t = ((const uint2*)(delta + (int64_t)row * d))[i];
-        dl[j] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
-                            __uint_as_float(t.y & 0xffff0000u));
+        N16<T>::up2(t.x, dl[j].x, dl[j].y);
+        N16<T>::up2(t.y, dl[j].z, dl[j].w);
       }
     }
     float4* xo = (float4*)(x_out + (int64_t)row * d);
@@ -227,11 +229,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
       if constexpr (sizeof(T) == 4) {
         ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
       } else {
-        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-        bf2 lo = {(__bf16)r0, (__bf16)r1}, hi = {(__bf16)r2, (__bf16)r3};
         uint2 p;
-        p.x = __builtin_bit_cast(uint32_t, lo);
-        p.y = __builtin_bit_cast(uint32_t, hi);
+        p.x = N16<T>::pk(r0, r1);
+        p.y = N16<T>::pk(r2, r3);
         ((uint2*)o)[i] = p;
       }
     }
@@ -257,6 +257,7 @@ void launch_layernorm_add(float* x, const T* delta, const float* gamma, const fl
 }
 template void launch_layernorm_add<float>(float*, const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm_add<bf16_t>(float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, hipStream_t);
+template void launch_layernorm_add<f16_t>(float*, const f16_t*, const float*, const float*, f16_t*, int, int, hipStream_t);
 // ------------------------------------------------------------------------------------------------
 // Decode-step LayerNorm (rows <= 128): one WORKGROUP per row, one float4 per thread, so the few rows of a decode
 // step spread over as many CUs as there are rows and every thread has a single round trip of (4 + n_slab)
@@ -294,10 +295,10 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
       v = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     } else {
       const uint2 a = ((const uint2*)er)[i], b = ((const uint2*)pr)[i];
-      v = make_float4(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16),
-                      __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u),
-                      __uint_as_float(a.y << 16) + __uint_as_float(b.y << 16),
-                      __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
+      float4 fa, fb;
+      N16<T>::up2(a.x, fa.x, fa.y); N16<T>::up2(a.y, fa.z, fa.w);
+      N16<T>::up2(b.x, fb.x, fb.y); N16<T>::up2(b.y, fb.z, fb.w);
+      v = make_float4(fa.x + fb.x, fa.y + fb.y, fa.z + fb.z, fa.w + fb.w);
     }
   } else {
     v = ((const float4*)(x + (int64_t)row * d))[i];
@@ -335,11 +336,9 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
   if constexpr (sizeof(T) == 4) {
     ((float4*)o)[i] = make_float4(r0, r1, r2, r3);
   } else {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    bf2 lo = {(__bf16)r0, (__bf16)r1}, hi = {(__bf16)r2, (__bf16)r3};
     uint2 p;
-    p.x = __builtin_bit_cast(uint32_t, lo);
-    p.y = __builtin_bit_cast(uint32_t, hi);
+    p.x = N16<T>::pk(r0, r1);
+    p.y = N16<T>::pk(r2, r3);
     ((uint2*)o)[i] = p;
   }
 }
@@ -357,27 +356,29 @@ void launch_layernorm_rows(const float* x, const float* gamma, const float* beta
 }
 template void launch_layernorm_rows<float>(const float*, const float*, const float*, float*, int, int, const LnPre&, hipStream_t);
 template void launch_layernorm_rows<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, const LnPre&, hipStream_t);
+template void launch_layernorm_rows<f16_t>(const float*, const float*, const float*, f16_t*, int, int, const LnPre&, hipStream_t);
 template void launch_layernorm<float>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, hipStream_t);
+template void launch_layernorm<f16_t>(const float*, const float*, const float*, f16_t*, int, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 // Weight intake: source layout (f32 or bf16 bits, as the checkpoint / the RCCL broadcast delivers it) -> f32 in the
 // engine's layout.  conv_in > 0: [out][in][3] -> [out][3][in]; `scale` folds the q pre-scaling (1/8: exact in bf16 too).
-__global__ void prep_weight_kernel(const void* __restrict__ src, int src_bf16, float* __restrict__ dst, int64_t n, int64_t conv_in,
-                                   float scale) {
+__global__ void prep_weight_kernel(const void* __restrict__ src, int src_type /*0 f32, 1 bf16 bits, 2 fp16 bits*/, float* __restrict__ dst,
+                                   int64_t n, int64_t conv_in, float scale) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t j = i;
     if (conv_in > 0) {  // i = (o*3 + k)*I + c  <-  (o*I + c)*3 + k
       const int64_t c = i % conv_in, ok = i / conv_in, k = ok % 3, o = ok / 3;
       j = (o * conv_in + c) * 3 + k;
     }
-    const float v = src_bf16 ? bf2f(((const bf16_t*)src)[j]) : ((const float*)src)[j];
+    const float v = src_type == 1 ? bf2f(((const bf16_t*)src)[j]) : (src_type == 2 ? N16<f16_t>::up(((const uint16_t*)src)[j]) : ((const float*)src)[j]);
     dst[i] = v * scale;
   }
 }
-void launch_prep_weight(const void* src, int src_bf16, float* dst, int64_t n, int64_t conv_in, float scale, hipStream_t s) {
+void launch_prep_weight(const void* src, int src_type, float* dst, int64_t n, int64_t conv_in, float scale, hipStream_t s) {
   int64_t nb = (n + 255) / 256; int blocks = (int)(nb < 8192 ? nb : 8192);
-  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, src, src_bf16, dst, n, conv_in, scale);
+  hipLaunchKernelGGL(prep_weight_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, src, src_type, dst, n, conv_in, scale);
 }
 
 template <typename T>
@@ -400,5 +401,7 @@ template <typename T> void launch_uncast(const T* in, float* out, int64_t n, hip
 }
 template void launch_cast<float>(const float*, float*, int64_t, hipStream_t);
 template void launch_cast<bf16_t>(const float*, bf16_t*, int64_t, hipStream_t);
+template void launch_cast<f16_t>(const float*, f16_t*, int64_t, hipStream_t);
 template void launch_uncast<float>(const float*, float*, int64_t, hipStream_t);
 template void launch_uncast<bf16_t>(const bf16_t*, float*, int64_t, hipStream_t);
+template void launch_uncast<f16_t>(const f16_t*, float*, int64_t, hipStream_t);

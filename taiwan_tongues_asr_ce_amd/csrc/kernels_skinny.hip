@@ -28,6 +28,7 @@
 #include <cstdlib>
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+template <typename T16>
 __global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int row_offset) {
   // one thread per 16-byte output chunk; rows past `rows` (padding of the last 32-row block) are left zero
   const int ks_per = K / 16;
@@ -41,19 +42,22 @@ __global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __res
     if (r >= rows) continue;
     const float* s = src + (int64_t)r * K + ks * 16 + 8 * (lane >> 5);
     uint4 o;
-    o.x = f2bf_pk(s[0], s[1]);
-    o.y = f2bf_pk(s[2], s[3]);
-    o.z = f2bf_pk(s[4], s[5]);
-    o.w = f2bf_pk(s[6], s[7]);
+    o.x = N16<T16>::pk(s[0], s[1]);
+    o.y = N16<T16>::pk(s[2], s[3]);
+    o.z = N16<T16>::pk(s[4], s[5]);
+    o.w = N16<T16>::pk(s[6], s[7]);
     ((uint4*)dst)[((int64_t)(nb + row_offset / 32) * ks_per + ks) * 64 + lane] = o;
   }
 }
-void launch_shuffle_cast(const float* src, bf16_t* dst_base, int rows, int K, int row_offset, hipStream_t s) {
+template <typename T16>
+void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s) {
   const int64_t n_chunks = (int64_t)((rows + 31) / 32) * (K / 16) * 64;
   const int64_t nb = (n_chunks + 255) / 256;
-  hipLaunchKernelGGL(shuffle_cast_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, dst_base, rows, K,
+  hipLaunchKernelGGL(shuffle_cast_kernel<T16>, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, (bf16_t*)dst_base, rows, K,
                      row_offset);
 }
+template void launch_shuffle_cast<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
+template void launch_shuffle_cast<f16_t>(const float*, f16_t*, int, int, int, hipStream_t);
 
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
@@ -63,7 +67,7 @@ int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (option we
 // ONE = the wave's k-steps fit one batch of loads (steps <= U): straight-line code.  (As a loop, the register reuse of
 // the next iteration forces an early s_waitcnt that, in the first iteration, waits for the bias / residual prefetch
 // before the bulk of the weight loads is even issued: one more serialised round trip.)
-template <int NW, int RB, int U, bool NT, bool ONE>
+template <typename T16, int NW, int RB, int U, bool NT, bool ONE>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh_, const bf16_t* __restrict__ x_,
                                                               int B_, int N_, int K_, int ksplit_, int steps_, GemmEpi e,
                                                               float* __restrict__ slab_, int64_t slab_stride_) {
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
       if (u < steps) {
 #pragma unroll
         for (int g = 0; g < RB; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g], 0, 0, 0);
+          acc[g] = N16<T16>::mfma32(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g]);
       }
   } else {
     prefetch_epilogue();
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
         if (i0 + u < steps) {
 #pragma unroll
           for (int g = 0; g < RB; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g], 0, 0, 0);
+            acc[g] = N16<T16>::mfma32(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g]);
         }
     }
   }
@@ -181,8 +185,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
       if (e.out_f32) *(float4*)(e.out_f32 + idx0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
       if (e.out_t) {
         uint2 pk;
-        pk.x = f2bf_pk(vv[0], vv[1]);
-        pk.y = f2bf_pk(vv[2], vv[3]);
+        pk.x = N16<T16>::pk(vv[0], vv[1]);
+        pk.y = N16<T16>::pk(vv[2], vv[3]);
         *(uint2*)((bf16_t*)e.out_t + idx0) = pk;
       }
       continue;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
           if (e.act == 1) o = gelu_erf(o);
           if (e.residual) o += e.residual[idx];
           if (e.out_f32) e.out_f32[idx] = o;
-          if (e.out_t) ((bf16_t*)e.out_t)[idx] = f2bf(o);
+          if (e.out_t) ((bf16_t*)e.out_t)[idx] = N16<T16>::down(o);
         }
       }
     }
@@ -233,8 +237,11 @@ int gemm_skinny_ksplit(int B, int N, int K, int want) {
 // Chooses the waves per workgroup so that each wave owns <= 10 k-steps (one round trip) where the shape allows.
 // ksplit > 1 (gemm_skinny_ksplit): partial tiles go to `slab`, bias / activation / residual are the consumer's job.
 // Returns false when the shape does not fit (caller falls back to gemm_basic).
-bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit,
+template <typename T16>
+bool launch_gemm_skinny(const T16* Wsh_, const T16* x_, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit,
                         float* slab, int64_t slab_stride) {
+  const bf16_t* Wsh = (const bf16_t*)Wsh_;   // raw 16-bit words: the kernel only moves them; T16 picks the MFMA form
+  const bf16_t* x = (const bf16_t*)x_;
   if (B < 1 || B > 128 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
   const int rb = (B + 31) / 32;  // 32-row groups sharing one weight stream
   const int n_blocks = (N + 31) / 32;
@@ -254,8 +261,8 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
   dim3 grid(n_blocks, ksplit);
 #define TTASR_SKINNY(NW_, RB_, U_, ONE_)                                                                                              \
   do {                                                                                                                                \
-    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
-    else hipLaunchKernelGGL((gemm_skinny_kernel<NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
+    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
   } while (0)
 #define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
   do {                                                                             \
@@ -279,3 +286,5 @@ bool launch_gemm_skinny(const bf16_t* Wsh, const bf16_t* x, int B, int N, int K,
 #undef TTASR_SKINNY
   return true;
 }
+template bool launch_gemm_skinny<bf16_t>(const bf16_t*, const bf16_t*, int, int, int, const GemmEpi&, hipStream_t, int, float*, int64_t);
+template bool launch_gemm_skinny<f16_t>(const f16_t*, const f16_t*, int, int, int, const GemmEpi&, hipStream_t, int, float*, int64_t);

@@ -93,15 +93,21 @@ def bucket_plan(sizes: Sequence[int], kinds: Sequence[int], bucket_bytes: int, e
 
 
 def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, np.ndarray]]], device=None,
-                      bucket_bytes: int = 256 << 20, bf16_matrices: bool = False) -> Iterator[Tuple[str, object]]:
+                      bucket_bytes: int = 256 << 20, bf16_matrices: bool = False, matrix_dtype: Optional[str] = None
+                      ) -> Iterator[Tuple[str, object]]:
     """Rank 0 supplies (name, array) in tensor_specs order; every rank yields every tensor once (bucket order - the engine's
     intake is keyed by name).  Tensors travel in ~256 MB buckets, one open bucket per dtype (few, large broadcasts: xGMI is
     point-to-point, so per-call latency and per-link bandwidth, not switch fan-out, set the cost).
 
     RCCL ("nccl") backend: the buckets live in device memory and are handed to the engine as DeviceTensor views - GPU to
-    GPU over xGMI, no host staging on the receiving ranks; with `bf16_matrices` (bf16 engines) the weight matrices are
-    rounded to bf16 ONCE on rank 0 and travel as bf16 (3.1 GB instead of 6.2 GB for large-v3; every rank, rank 0
-    included, loads the same bits).  gloo backend (CPU tests): float32 host buckets, host arrays out."""
+    GPU over xGMI, no host staging on the receiving ranks; with matrix_dtype "bf16" / "f16" (16-bit engines;
+    `bf16_matrices=True` is the older spelling of "bf16") the weight matrices are rounded to that type ONCE on rank 0 and
+    travel as 16-bit words (3.1 GB instead of 6.2 GB for large-v3; every rank, rank 0 included, loads the same bits).
+    gloo backend (CPU tests): float32 host buckets, host arrays out."""
+    if matrix_dtype is None and bf16_matrices:
+        matrix_dtype = "bf16"
+    if matrix_dtype not in (None, "bf16", "f16"):
+        raise ValueError(f"matrix_dtype={matrix_dtype!r}")
     if not dist.is_initialized():
         yield from src_iter
         return
@@ -111,9 +117,10 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
     dev = torch.device(f"cuda:{device}") if on_dev else torch.device("cpu")
     specs = synth.tensor_specs(dims)
     sizes = [int(np.prod(sp[1])) for sp in specs]
-    kinds = [1 if (on_dev and bf16_matrices and _is_matrix(sp[0], sp[1])) else 0 for sp in specs]
+    kinds = [1 if (on_dev and matrix_dtype and _is_matrix(sp[0], sp[1])) else 0 for sp in specs]
     esz = (4, 2)
-    dts = (torch.float32, torch.bfloat16)
+    dts = (torch.float32, torch.float16 if matrix_dtype == "f16" else torch.bfloat16)
+    codes = (0, 2 if matrix_dtype == "f16" else 1)     # TTASR_DTYPE_F32 / _BF16 / _F16
     plan = bucket_plan(sizes, kinds, bucket_bytes, esz)
     where = {}                                  # tensor index -> (bucket, element offset)
     for b, idx in enumerate(plan):
@@ -135,7 +142,7 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
         if on_dev:
             torch.cuda.synchronize(dev)       # the engine reads the bucket on its own stream
             for k in plan[b]:
-                yield specs[k][0], DeviceTensor(flat.data_ptr() + where[k][1] * esz[k0], k0, tuple(specs[k][1]))
+                yield specs[k][0], DeviceTensor(flat.data_ptr() + where[k][1] * esz[k0], codes[k0], tuple(specs[k][1]))
         else:
             host = flat.numpy()
             for k in plan[b]:
@@ -157,8 +164,9 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
 
 
 def broadcast_weights(engine, dims: WhisperDims, src_iter, device=None):
-    from .config import COMPUTE_BF16
-    engine.load_weights(broadcast_tensors(dims, src_iter, device, bf16_matrices=engine.compute_type == COMPUTE_BF16))
+    from .config import COMPUTE_BF16, COMPUTE_F16
+    md = {COMPUTE_BF16: "bf16", COMPUTE_F16: "f16"}.get(engine.compute_type)
+    engine.load_weights(broadcast_tensors(dims, src_iter, device, matrix_dtype=md))
 
 
 def gather_tokens(tokens: Sequence[Sequence[int]], max_len: int, device=None, pad: int = -1) -> np.ndarray:

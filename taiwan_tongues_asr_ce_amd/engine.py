@@ -9,7 +9,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from .config import COMPUTE_BF16, COMPUTE_F32, NON_SPEECH_TOKENS_MULTI, SpecialTokens, WhisperDims
+from .config import COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, NON_SPEECH_TOKENS_MULTI, SpecialTokens, WhisperDims
 
 
 class TtasrError(RuntimeError):
@@ -18,7 +18,7 @@ class TtasrError(RuntimeError):
 
 @dataclass
 class DeviceTensor:
-    """A tensor in device memory of the engine's GPU: address, TTASR_DTYPE_* (0 float32, 1 bfloat16 bits), shape."""
+    """A tensor in device memory of the engine's GPU: address, TTASR_DTYPE_* (0 float32, 1 bfloat16 bits, 2 float16 bits), shape."""
     ptr: int
     dtype: int
     shape: Tuple[int, ...]

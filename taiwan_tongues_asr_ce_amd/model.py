@@ -20,7 +20,7 @@ from typing import Dict, Iterable, Iterator, List, NamedTuple, Optional, Sequenc
 import numpy as np
 
 from . import alignment, ct2, synth, vad
-from .config import (COMPUTE_BF16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
+from .config import (COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, HOP, N_FRAMES, N_SAMPLES, PRESETS, SAMPLE_RATE, SpecialTokens,
                      WhisperDims)
 from .tokenizer import load_tokenizer
 
@@ -59,9 +59,11 @@ class TranscriptionInfo:
 
 _COMPUTE_ALIASES = {
     "float32": COMPUTE_F32, "fp32": COMPUTE_F32,
-    # the engine's 16-bit type is bf16; fp16 / int8 requests run as bf16 (documented in DESIGN.md)
-    "bfloat16": COMPUTE_BF16, "bf16": COMPUTE_BF16, "float16": COMPUTE_BF16, "fp16": COMPUTE_BF16,
-    "int8_float16": COMPUTE_BF16, "int8_bfloat16": COMPUTE_BF16, "int8": COMPUTE_BF16, "default": COMPUTE_BF16,
+    # "float16" is the reference's GPU setting (asr_core.py:141, api/config.py:12, faster_whisper_asr.py:95) and means what it
+    # says: fp16 weights / activations, f32 accumulation.  The int8 variants have no int8 weight path here: they run with
+    # 16-bit weights of the named activation type (a superset in precision), with a warning.
+    "bfloat16": COMPUTE_BF16, "bf16": COMPUTE_BF16, "float16": COMPUTE_F16, "fp16": COMPUTE_F16,
+    "int8_float16": COMPUTE_F16, "int8_bfloat16": COMPUTE_BF16, "int8": COMPUTE_F16, "default": COMPUTE_BF16,
     "auto": COMPUTE_BF16,
 }
 
@@ -199,11 +201,12 @@ class WhisperModel:
                 with open(gc_path, "r", encoding="utf-8") as f:
                     heads = json.load(f).get("alignment_heads")
         self.alignment_heads = [tuple(h) for h in heads] if heads else alignment.default_alignment_heads(dims.dec_layers, dims.n_heads)
-        if compute_type in ("float16", "fp16", "int8_float16", "int8_bfloat16", "int8"):
-            # the reference asks for float16 on GPU (asr_core.py:141) and int8 on CPU (api/file_asr.py:188); this engine's
-            # 16-bit type is bfloat16 and it has no int8 path - say so instead of silently computing in another type
-            warnings.warn(f"compute_type={compute_type!r} is not implemented by this engine: computing in bfloat16 "
-                          "(bf16 weights and activations, f32 accumulation, LayerNorm and softmax)", stacklevel=2)
+        if compute_type in ("int8_float16", "int8_bfloat16", "int8"):
+            # the reference asks for int8 on CPU (api/file_asr.py:188); there is no int8 weight path on this engine - say so
+            # instead of silently computing in another type
+            warnings.warn(f"compute_type={compute_type!r}: int8 weights are not implemented by this engine; computing with "
+                          f"{'bfloat16' if 'bfloat16' in compute_type else 'float16'} weights and activations "
+                          "(f32 accumulation, LayerNorm and softmax)", stacklevel=2)
         self.engine = (_engine_factory or Engine)(dims, _COMPUTE_ALIASES[compute_type], max_batch, device_index)
         self.engine.load_weights(tensors)
         self.special = self.engine.special

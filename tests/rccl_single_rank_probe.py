@@ -18,23 +18,28 @@ def main():
     import torch
     import torch.distributed as dist
     from taiwan_tongues_asr_ce_amd import synth
-    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F32, PRESETS
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, PRESETS
     from taiwan_tongues_asr_ce_amd.dist import barrier, broadcast_weights, gather_logits, gather_tokens, init_process_group
     from taiwan_tongues_asr_ce_amd.engine import Engine
     rank, world, local = init_process_group()
     out = {"backend": dist.get_backend(), "world": world}
     dims = PRESETS["tiny"]
     clips = [synth.noise_clip(0), synth.tonal_clip(1)]
-    for compute, tag in ((COMPUTE_BF16, "bf16"), (COMPUTE_F32, "f32")):
+    for compute, tag in ((COMPUTE_BF16, "bf16"), (COMPUTE_F16, "f16"), (COMPUTE_F32, "f32")):
         res = []
         for route in ("host", "rccl"):
             e = Engine(dims, compute, 2, device=local)
             if route == "host":
-                e.load_weights(synth.iter_weights(dims))
+                if compute == COMPUTE_F16:   # the broadcast rounds the matrices to fp16 once on rank 0: give the host route the same values
+                    from taiwan_tongues_asr_ce_amd.dist import _is_matrix
+                    e.load_weights((n, a.astype(np.float16).astype(np.float32) if _is_matrix(n, a.shape) else a)
+                                   for n, a in synth.iter_weights(dims))
+                else:
+                    e.load_weights(synth.iter_weights(dims))
             else:   # small buckets: several broadcasts per dtype
                 from taiwan_tongues_asr_ce_amd.dist import broadcast_tensors
                 e.load_weights(broadcast_tensors(dims, synth.iter_weights(dims), local, bucket_bytes=8 << 20,
-                                                 bf16_matrices=compute == COMPUTE_BF16))
+                                                 matrix_dtype={COMPUTE_BF16: "bf16", COMPUTE_F16: "f16"}.get(compute)))
             st = e.special
             e.log_mel(clips, want_output=False)
             enc = e.encode(2, want_output=True)

@@ -1,0 +1,191 @@
+"""GPU: the fp16 compute mode (TTASR_COMPUTE_F16) - what `compute_type="float16"`, the setting of every GPU call site of the
+reference (asr_core.py:141, api/config.py:12, faster_whisper_asr.py:95), means on this engine: fp16 weights and activations,
+f32 accumulation / LayerNorm / softmax / residual stream, the SAME kernels and schedules as the bf16 mode with the f16 forms of
+the MFMAs.  fp16 carries 3 more mantissa bits than bf16, so every tolerance here is <= 1/4 of its bf16 counterpart:
+  logits 0.015 (bf16 0.06) at tiny, 0.02 (bf16 0.08) at large-v3 width; token equality wherever the reference margin exceeds
+  2 x that (0.03 / 0.04).  Gates: golden set G7 (HF's own fp16 arithmetic, tests/golden/tiny_f16.npz) and the oracle holding
+  fp16-rounded weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_ref as R
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_F16, PRESETS
+
+from oracle_checks import encode_chunked, teacher_forced
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+F16_TOL = 0.015
+
+
+def _engine(name, max_batch):
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    e = Engine(PRESETS[name], COMPUTE_F16, max_batch)
+    e.load_weights(synth.iter_weights(PRESETS[name]))
+    return e
+
+
+CLIPS4 = [lambda: synth.noise_clip(0), lambda: synth.tonal_clip(1), lambda: synth.noise_clip(2), lambda: synth.burst_clip(3)]
+
+
+@pytest.mark.parametrize("tag", ["ts", "nots"])
+def test_tiny_f16_tokens_equal_hf_f16_golden(golden_dir, tag):
+    """G7: the fp16 engine's greedy tokens are IDENTICAL to HF-fp16's up to the first step at which HF's own top-2 margin is
+    within 2 x the stated fp16 tolerance; strided logits of the prompt's last position within the tolerance of HF's."""
+    g = np.load(os.path.join(golden_dir, "tiny_f16.npz"))
+    clips = [c() for c in CLIPS4]
+    e = _engine("tiny", 4)
+    e.log_mel(clips, want_output=False)
+    enc = e.encode(4, want_output=True)
+    np.testing.assert_allclose(enc[:, ::25, ::3], g["enc_stride"], atol=0.04)          # bf16: 0.15
+    prompt = g[f"{tag}_prompt"].tolist()
+    e.decode_reset(4)
+    lg = None
+    for t in prompt:
+        lg = e.decode_step([t] * 4)
+    np.testing.assert_allclose(lg[:, ::97], g[f"{tag}_logits_stride"][0], atol=F16_TOL)
+    toks, margin = g[f"{tag}_tokens"], g[f"{tag}_margin"]
+    opts = e.gen_opts(toks.shape[0], tag == "ts", suppress=g["suppress"].tolist(), begin_suppress=g["begin_suppress"].tolist())
+    res = e.generate([prompt] * 4, opts)
+    again = e.generate([prompt] * 4, opts)
+    assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
+    equal = 0
+    for b in range(4):
+        for i in range(toks.shape[0]):
+            if i >= len(res.tokens[b]) or res.tokens[b][i] != toks[i, b]:
+                assert margin[i, b] <= 2 * F16_TOL, (tag, b, i, float(margin[i, b]))
+                break
+            equal += 1
+    assert equal >= 0.75 * toks.size, equal
+    e.close()
+
+
+def test_tiny_f16_against_the_oracle_with_f16_rounded_weights():
+    pd = PRESETS["tiny"]
+    dims = R.Dims(**pd.as_dict())
+    Wh = R.to_torch(synth.state_dict(pd), round_f16=True)
+    clips = [c() for c in CLIPS4]
+    e = _engine("tiny", 4)
+    st = e.special
+    mel = e.log_mel(clips)
+    mel_ref = np.stack([R.log_mel(c, 80) for c in clips])
+    np.testing.assert_allclose(mel, mel_ref, atol=2e-4)
+    enc = e.encode(4, want_output=True)
+    enc_ref = R.encoder_forward(torch.from_numpy(mel_ref), Wh, dims)
+    err = np.abs(enc - enc_ref.numpy())
+    assert err.max() < 0.04 and err.mean() < 0.003, (float(err.max()), float(err.mean()))     # bf16: 0.15 / 0.01
+    for layer in (0, dims.dec_layers - 1):          # cross-KV against the oracle's (values of LayerNorm scale)
+        kv = R.cross_kv(enc_ref, Wh, dims)[layer]
+        for which in (0, 1):
+            assert np.abs(e.cross_kv(layer, which, 4) - kv[which].numpy()).max() < 0.04
+    prompt = [st.sot, st.lang_zh, st.transcribe]
+    xkv = R.cross_kv(enc_ref, Wh, dims)
+    cache = R.SelfCache.empty(dims.dec_layers)
+    e.decode_reset(4)
+    for t in prompt + [50400, 1234]:
+        lg = e.decode_step([t] * 4)
+        want = R.decoder_forward(torch.full((4, 1), t), cache, xkv, Wh, dims)[:, 0].numpy()
+        assert np.abs(lg - want).max() < F16_TOL
+    opts = e.gen_opts(24, True)
+    res = e.generate([prompt] * 4, opts)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
+    g = teacher_forced(res.tokens, prompt, enc_ref, Wh, dims, rules, tol=2 * F16_TOL, margin=2 * F16_TOL)
+    assert g.n_clear >= 0.85 * g.n_steps, g
+    # beam search, sampling and a previous-text prompt (prefill pass) run in fp16 and replay bit-identically
+    b1 = e.generate_beam([prompt] * 2, 2, e.gen_opts(8, True))
+    b2 = e.generate_beam([prompt] * 2, 2, e.gen_opts(8, True))
+    assert b1.tokens == b2.tokens and np.array_equal(b1.sum_logprob, b2.sum_logprob)
+    long_prompt = [st.sot_prev] + list(range(1000, 1040)) + prompt
+    p1 = e.generate([long_prompt] * 4, e.gen_opts(6, True, sot_index=41))
+    p2 = e.generate([long_prompt] * 4, e.gen_opts(6, True, sot_index=41))
+    assert p1.tokens == p2.tokens and all(len(t) > 0 for t in p1.tokens)
+    e.close()
+
+
+def test_f16_measured_shape_b32_token_equality_under_margin():
+    """large-v3 WIDTH (2 + 2 layers), B = 32 unshared rows: the single-pass cross-attention, identity-page self-attention and
+    32-row decode GEMMs in their f16 instantiations.  Logits within 0.02 (bf16 gate: 0.08), teacher-forced token equality at
+    margins > 0.04 on at least 60 % of the steps."""
+    pd = PRESETS["large-v3-w2"]
+    rd = R.Dims(**pd.as_dict())
+    sd = synth.state_dict(pd)
+    Wh = R.to_torch(sd, round_f16=True)
+    kinds = (synth.noise_clip, synth.tonal_clip, synth.noise_clip, synth.burst_clip)
+    B = 32
+    clips = [kinds[i % 4](100 + i) for i in range(B)]
+    mel_ref = np.stack([R.log_mel(c, pd.n_mels) for c in clips])
+    enc_ref = encode_chunked(mel_ref, Wh, rd)
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    e = Engine(pd, COMPUTE_F16, B)
+    e.load_weights(sd.items())
+    st = e.special
+    e.log_mel(clips, want_output=False)
+    enc = e.encode(B, want_output=True)
+    err = np.abs(enc - enc_ref.numpy())
+    assert err.max() < 0.04 and err.mean() < 0.003, (float(err.max()), float(err.mean()))
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    xkv = R.cross_kv(enc_ref, Wh, rd)
+    cache = R.SelfCache.empty(rd.dec_layers)
+    e.decode_reset(B)
+    for t in prompt + [1234]:
+        lg = e.decode_step([t] * B)
+        want = R.decoder_forward(torch.full((B, 1), t), cache, xkv, Wh, rd)[:, 0].numpy()
+        assert np.abs(lg - want).max() < 0.02, (t, float(np.abs(lg - want).max()))
+    opts = e.gen_opts(8, False, check_interval=1)
+    res = e.generate([prompt] * B, opts)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=False)
+    g = teacher_forced(res.tokens, prompt, enc_ref, Wh, rd, rules, tol=0.04, margin=0.04)
+    assert g.n_clear >= 0.6 * g.n_steps, g
+    again = e.generate([prompt] * B, opts)
+    assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
+    e.close()
+
+
+def test_f16_device_intake_and_facade():
+    """fp16 bits handed over in device memory (TTASR_DTYPE_F16: what the RCCL broadcast delivers to an fp16 engine) load
+    bit-identically to the host intake of the same fp16-representable values (the broadcast rounds the matrices ONCE on rank 0
+    and every rank loads those bits; unlike bf16, rounding an arbitrary f32 weight before or after the 1/8 query pre-scaling is
+    not the same thing in fp16 - the scaled value can be subnormal); WhisperModel(compute_type="float16") builds the fp16 engine."""
+    from taiwan_tongues_asr_ce_amd.dist import _is_matrix
+    from taiwan_tongues_asr_ce_amd.engine import DeviceTensor, Engine
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    dims = PRESETS["tiny"]
+    clips = [synth.noise_clip(0), synth.tonal_clip(1)]
+    outs = []
+    for route in ("host", "device"):
+        e = Engine(dims, COMPUTE_F16, 2)
+        if route == "host":
+            e.load_weights((n, a.astype(np.float16).astype(np.float32) if _is_matrix(n, a.shape) else a) for n, a in synth.iter_weights(dims))
+        else:
+            keep = []
+
+            def views():
+                for name, arr in synth.iter_weights(dims):
+                    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).cuda()
+                    half = _is_matrix(name, arr.shape)
+                    if half:
+                        t = t.to(torch.float16)
+                    torch.cuda.synchronize()
+                    keep.append(t)
+                    yield name, DeviceTensor(t.data_ptr(), 2 if half else 0, tuple(arr.shape))
+            e.load_weights(views())
+        st = e.special
+        e.log_mel(clips, want_output=False)
+        enc = e.encode(2, want_output=True)
+        e.decode_reset(2)
+        lg = [e.decode_step([t, t]) for t in (st.sot, st.lang_zh, st.transcribe)]
+        outs.append((enc, lg))
+        e.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    m = WhisperModel("synthetic:tiny", device="cuda", compute_type="float16", max_batch=5)
+    assert m.engine.compute_type == COMPUTE_F16
+    segs, info = m.transcribe(synth.noise_clip(3, 160000), language="zh", beam_size=5, vad_filter=False)
+    assert info.language == "zh" and isinstance(list(segs), list)

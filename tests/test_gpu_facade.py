@@ -109,10 +109,16 @@ def test_beam_that_does_not_fit_is_refused_not_degraded():
         m.transcribe(np.zeros(1600, np.float32), language="zh", beam_size=5)
     with pytest.raises(ValueError, match="at most 7"):
         m.transcribe(np.zeros(1600, np.float32), language="zh", beam_size=9)
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F16
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        WhisperModel("synthetic:micro", device="cuda", compute_type="float16", max_batch=1)
-    assert any("computing in bfloat16" in str(x.message) for x in w)
+        m16 = WhisperModel("synthetic:micro", device="cuda", compute_type="float16", max_batch=1)
+        m8 = WhisperModel("synthetic:micro", device="cuda", compute_type="int8_bfloat16", max_batch=1)
+    # "float16" - the reference's GPU setting - is a real fp16 mode (no substitution, no warning); the int8 variants say
+    # that their weights stay 16-bit
+    assert m16.engine.compute_type == COMPUTE_F16 and m8.engine.compute_type == COMPUTE_BF16
+    assert not any("float16" in str(x.message) and "not implemented" in str(x.message) for x in w)
+    assert any("int8 weights are not implemented" in str(x.message) for x in w)
 
 
 def test_fallback_ladder_runs_and_reports_temperature(model):

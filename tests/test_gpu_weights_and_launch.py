@@ -85,15 +85,16 @@ def test_rccl_transport_runs_on_one_rank():
     """the on-device broadcast branch of dist.broadcast_tensors, the device-tensor gathers and the
     RCCL barrier had never executed anywhere.  A ONE-rank "nccl" process group (TTASR_DIST_FORCE=1; RCCL accepts a single rank
     per device) runs exactly those calls on this box: the engine loaded through the RCCL buckets is bit-identical (encoder
-    output, logits, tokens) to the engine loaded from host arrays, in bf16 (matrices travel as bf16) and f32."""
+    output, logits, tokens) to the engine loaded from host arrays, in bf16 / fp16 (matrices travel as 16-bit words) and f32."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TTASR_DIST_BACKEND")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_probe.py")], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["backend"] == "nccl" and out["world"] == 1
-    for k in ("bf16_encoder_equal", "bf16_logits_equal", "bf16_tokens_equal", "f32_encoder_equal", "f32_logits_equal",
-              "f32_tokens_equal", "gather_tokens", "gather_logits", "broadcast_weights_runs"):
+    for k in ("bf16_encoder_equal", "bf16_logits_equal", "bf16_tokens_equal", "f16_encoder_equal", "f16_logits_equal",
+              "f16_tokens_equal", "f32_encoder_equal", "f32_logits_equal", "f32_tokens_equal", "gather_tokens", "gather_logits",
+              "broadcast_weights_runs"):
         assert out[k] is True, (k, out)
 
 
