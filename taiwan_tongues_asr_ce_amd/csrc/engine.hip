@@ -96,7 +96,9 @@ struct ttasr_ctx {
   int ks_want[4] = {0, 0, 0, 0};  // option ksplit_out / _q / _qkv / _fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
   int gemm_force = 0;         // option enc_gemm = 1|2|3 (A/B testing of the encoder GEMM kernels)
   bool no_flash = false;      // option flash = 0
-  int prefill_ns_min = 16;    // option prefill_ns_min: shortest prompt whose sot position is taken from the prefill pass
+  int prefill_ns_min = 2;     // option prefill_ns_min: shortest prompt (positions before the last) whose <|startoftranscript|> position is taken
+                              // from the prefill pass.  Round 3: 2 (was 16) - the small prefill pass now runs the decode-step launch plan
+                              // (K-split GEMMs), so 3 prompt positions x 32 clips cost 6.4 ms against 8.8 ms as three steps
   bool enc_res_epilogue = false;  // option enc_residual_epilogue: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
   RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
@@ -647,21 +649,65 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
   // up to 128 rows (short prompts: a handful of positions x the clips of a pass) the fragment-packed decode GEMM streams each
   // weight once for all rows; beyond that the rows are a real M dimension for the tiled encoder GEMMs
   const bool small = n <= 128 && !c->force_basic && !c->prefill_tiled;
+  // Round 3: the small pass runs the DECODE-STEP launch plan - every GEMM whose consumer can add partial results is cut into K
+  // slices (160-320 workgroups instead of 40 of them pulling 164-656 KB each: a CU takes in ~25 GB/s of cold bytes), the
+  // partial tiles go to the f32 slabs, and the per-row LayerNorm / the cross-attention kernel sum them in slab order (no
+  // atomics: bit-reproducible).  A 3-position prompt of 32 clips then costs about 1.3 decode steps instead of 3.
+  const bool slabbed = small && sizeof(T) == 2;
+  const int64_t slab_cap = (int64_t)16 * c->maxB * 3 * d;   // floats in c->slab
+  struct { const float* bias = nullptr; int n_slab = 0; int64_t stride = 0; } pend;
   auto pgemm = [&](const GemmArgs& g, const void* Wsh) {
     if constexpr (sizeof(T) == 2) {
       if (small && Wsh && launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, s)) return;
     }
     gemm<T>(c, g);
   };
+  // K-split GEMM into slabs [ks][n][N]; returns the slab descriptor (n == 0: not split, the caller runs the GEMM whole)
+  auto split_gemm = [&](const GemmArgs& g, const void* Wsh, const float* bias, int max_ks) -> SlabIn {
+    SlabIn si;
+    if constexpr (sizeof(T) == 2) {
+      if (slabbed && Wsh) {
+        int ks = gemm_skinny_ksplit(n, g.N, g.K, 0);
+        if (ks > max_ks) ks = gemm_skinny_ksplit(n, g.N, g.K, max_ks);
+        const int64_t stride = (int64_t)n * g.N;
+        GemmEpi ep; ep.ldc = g.N;
+        if (ks > 1 && ks * stride <= slab_cap &&
+            launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, n, g.N, g.K, ep, s, ks, c->slab, stride)) {
+          si.slab = c->slab; si.bias = bias; si.n = ks; si.stride = stride; si.ld = g.N;
+        }
+      }
+    }
+    return si;
+  };
+  auto ln = [&](const float* g_, const float* b_) {
+    if (slabbed) {
+      LnPre pre; pre.x_out = x;
+      if (pend.n_slab) { pre.bias = pend.bias; pre.slab = c->slab; pre.n_slab = pend.n_slab; pre.slab_stride = pend.stride; }
+      launch_layernorm_rows<T>(x, g_, b_, (T*)h, n, d, pre, s);
+      pend.bias = nullptr; pend.n_slab = 0;
+    } else {
+      launch_layernorm<T>(x, g_, b_, (T*)h, n, d, s);
+    }
+  };
+  auto residual_gemm = [&](const void* A, const void* W, const void* Wsh, const float* bias, int K) {   // x += W a + b
+    GemmArgs g = lin_args<T>(A, W, n, d, K);
+    const SlabIn si = split_gemm(g, Wsh, bias, 16);
+    if (si.n) { pend.bias = bias; pend.n_slab = si.n; pend.stride = si.stride; return; }
+    g.epi.bias = bias; g.epi.residual = x; g.epi.out_f32 = x;
+    pgemm(g, Wsh);
+  };
   for (int l = 0; l < c->cfg.dec_layers; ++l) {
     const DecLayerW& L = c->dec[l];
-    launch_layernorm<T>(x, L.ln1g, L.ln1b, (T*)h, n, d, s);
+    ln(L.ln1g, L.ln1b);
     { GemmArgs g = lin_args<T>(h, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = qkv; pgemm(g, L.wqkv_sh); }
     launch_self_attn_prefill<T>((const T*)qkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
                                 c->identity_pages, (T*)att, n_seq, npos, c->H, s);
-    { GemmArgs g = lin_args<T>(att, L.wo, n, d, d); g.epi.bias = L.bo; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.wo_sh); }
-    launch_layernorm<T>(x, L.ln2g, L.ln2b, (T*)h, n, d, s);
-    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d); g.epi.bias = L.bqx; g.epi.out_t = qkv; pgemm(g, L.wqx_sh); }  // q reuses the qkv buffer
+    residual_gemm(att, L.wo, L.wo_sh, L.bo, d);
+    ln(L.ln2g, L.ln2b);
+    SlabIn sq;   // the query of the cross-attention: K-split too when its consumer can sum slabs (not the alignment pass)
+    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d);
+      if (!al && npos * seq_per_clip < 32) sq = split_gemm(g, L.wqx_sh, L.bqx, 4);   // >= 32 rows per clip: the MFMA flash pass reads T rows
+      if (!sq.n) { g.epi.bias = L.bqx; g.epi.out_t = qkv; pgemm(g, L.wqx_sh); } }  // q reuses the qkv buffer
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
     if (al) {
       const T* Kc = Kx + (int64_t)al->clip * c->H * c->T * 64;
@@ -669,13 +715,16 @@ void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_pr
                                  al->probs, s);
     } else {
       launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws, SlabIn{}, c->maxB);
+                                  c->no_xsplit ? nullptr : c->xsplit_ws, sq, c->maxB);
     }
-    { GemmArgs g = lin_args<T>(att, L.wox, n, d, d); g.epi.bias = L.box; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.wox_sh); }
-    launch_layernorm<T>(x, L.ln3g, L.ln3b, (T*)h, n, d, s);
+    residual_gemm(att, L.wox, L.wox_sh, L.box, d);
+    ln(L.ln3g, L.ln3b);
     { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; pgemm(g, L.w1_sh); }
-    { GemmArgs g = lin_args<T>(mid, L.w2, n, d, ffn); g.epi.bias = L.b2; g.epi.residual = x; g.epi.out_f32 = x; pgemm(g, L.w2_sh); }
+    residual_gemm(mid, L.w2, L.w2_sh, L.b2, ffn);
   }
+  // callers read the finished residual rows from c->x (no-speech probability, token log-probs of the alignment pass): fold the
+  // last fc2's partial tiles in (the final decoder LayerNorm does it; its normalised output lands in h and is not used here)
+  if (pend.n_slab) ln(c->dlnf_g, c->dlnf_b);
 }
 
 // How many leading prompt positions can be prefilled: every row must still have a forced token after them and the rows

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "auto": {},                                            # default plan: K slices chosen automatically (d 4, q 4, qkv 2, fc2 8)
-    "prefill_sot": {"prefill_ns_min": 2},
+    "steps_for_prompt": {"prefill_ns_min": 16},          # round-2 default: the 4-token prompt fed as four decode steps
     "d5": {"ksplit_out": 5, "ksplit_q": 5, "ksplit_qkv": 2, "ksplit_fc2": 8},
     "f16": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 16},
     "f10": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 10},
@@ -30,7 +30,7 @@ VARIANTS = {
     "w_plain": {"weights_nontemporal": 0},
     "xattn_plain": {"xattn_nontemporal": 0},
 }
-DEFAULTS = {"prefill_ns_min": 16, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
+DEFAULTS = {"prefill_ns_min": 2, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
             "xattn_nontemporal": 1}
 
 
