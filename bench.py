@@ -450,9 +450,10 @@ def main():
         gs = [eng.bench_kernel(n, B, iters=30) for n in names]
         enc_tf = sum(x["flops"] for x in gs) / (sum(x["ms"] for x in gs) * 1e-3) / 1e12
         # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent; static, like traffic)
-        pmc_busy = None
+        pmc_busy, pmc_file = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r2_pmc.json")) as f:
+            pmc_file = next(f_ for f_ in ("r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 kk_ = json.load(f)["kernels"]
 
             def busy(prefix, grid):
@@ -503,7 +504,7 @@ def main():
                      "encoder_phase_frac": round(enc_phase_flops / (ph["encoder"] * 1e-3) / 2.5e15, 4),
                      "cross_kv_phase_frac": round(cls_flops["cross_kv"] / (ph["cross_kv"] * 1e-3) / 2.5e15, 4),
                      "isolated_relaunch_tflops": round(enc_tf, 1), "isolated_relaunch_frac": round(enc_tf / 2500.0, 4),
-                     "pmc_mfma_busy_frac": pmc_busy, "pmc_source": "profiles/r2_pmc.json (static)"},
+                     "pmc_mfma_busy_frac": pmc_busy, "pmc_source": f"profiles/{pmc_file} (static)" if pmc_busy is not None else None},
         }
         if world == 1 and C_ == 1 and args.clips == "noise":
             # SURVEY.md 8(d)'s tonal variant (five sines: exercises the per-clip max - 8 clamp of the log-mel): the same step on
