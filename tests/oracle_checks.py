@@ -35,16 +35,29 @@ def encode_chunked(mel: np.ndarray, W, rd, chunk: int = 4) -> torch.Tensor:
     return torch.cat(outs, dim=0)
 
 
-def teacher_forced(tokens: Sequence[Sequence[int]], prompt: Sequence[int], enc_ref: torch.Tensor, W, rd, rules, tol: float,
-                   margin: float, n_check: int | None = None) -> Graded:
-    """Grade rows `tokens[b]` (engine output for clip b of enc_ref) as described in the module docstring."""
-    B = len(tokens)
-    assert enc_ref.shape[0] == B
+def prompt_state(prompt: Sequence[int], enc_ref: torch.Tensor, W, rd):
+    """(cross-KV, self-attention cache after the prompt, logits of its last position, logits of every prompt position): the part
+    of a grading that does not depend on the graded tokens - compute it once per clip and hand it to several teacher_forced()
+    calls (the full-depth oracle reads 3.6 GB of decoder weights per position)."""
+    B = enc_ref.shape[0]
     xkv = R.cross_kv(enc_ref, W, rd)
     cache = R.SelfCache.empty(rd.dec_layers)
-    logits = None
+    per_pos = []
     for t in prompt:
-        logits = R.decoder_forward(torch.full((B, 1), int(t), dtype=torch.long), cache, xkv, W, rd)[:, 0]
+        per_pos.append(R.decoder_forward(torch.full((B, 1), int(t), dtype=torch.long), cache, xkv, W, rd)[:, 0])
+    return xkv, cache, per_pos[-1], per_pos
+
+
+def teacher_forced(tokens: Sequence[Sequence[int]], prompt: Sequence[int], enc_ref: torch.Tensor, W, rd, rules, tol: float,
+                   margin: float, n_check: int | None = None, start=None) -> Graded:
+    """Grade rows `tokens[b]` (engine output for clip b of enc_ref) as described in the module docstring.  `start` = a
+    prompt_state() result to reuse (its cache is not modified: decoder_forward replaces cache entries, never writes in place)."""
+    B = len(tokens)
+    assert enc_ref.shape[0] == B
+    if start is None:
+        start = prompt_state(prompt, enc_ref, W, rd)
+    xkv, cache0, logits = start[0], start[1], start[2]
+    cache = R.SelfCache(list(cache0.k), list(cache0.v))
     n = min(len(t) for t in tokens)
     if n_check is not None:
         n = min(n, n_check)

@@ -155,3 +155,54 @@ def test_c2_whisper_small_full_depth_batch8_properties():
     rev = e.generate([prompt] * B, opts)
     assert rev.tokens[::-1] == res.tokens and np.array_equal(rev.sum_logprob[::-1], res.sum_logprob)
     e.close()
+
+
+def test_c2_whisper_small_full_depth_batch8_against_the_oracle():
+    """BASELINE.json configs[1] (whisper-small bf16, batch 8 x 30 s, 1 GPU) held to the ORACLE at its full size - 12 + 12 layers,
+    8 different clips: the f32 engine within the north-star tolerance (encoder and prompt logits 1e-3, greedy tokens identical on
+    every row; 4 clips, to bound the oracle's host time), the bf16 engine (the measured mode, all 8 clips) with logits within 0.08 of the oracle holding the bf16-rounded weights and
+    teacher-forced token equality wherever the oracle's top-2 margin exceeds 0.16 (>= 60 % of the steps)."""
+    import torch
+    from oracle import whisper_ref as R
+    from oracle_checks import encode_chunked, teacher_forced
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_F32
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    torch.set_grad_enabled(False)
+    dims = PRESETS["small"]
+    rd = R.Dims(**dims.as_dict())
+    B, n_new = 8, 8
+    sd = synth.state_dict(dims)
+    kinds = (synth.noise_clip, synth.tonal_clip, synth.burst_clip, synth.noise_clip)
+    clips = [kinds[i % 4](500 + i) for i in range(B)]
+    mel_ref = np.stack([R.log_mel(c, dims.n_mels) for c in clips])
+    clips_all, mel_all = clips, mel_ref
+    # the measured mode (bf16) at the configuration's full batch of 8; the f32 parity mode on the first 4 clips (host time)
+    for compute, W, tol_enc, tol_logit, B in ((COMPUTE_F32, R.to_torch(sd), 1e-3, 1e-3, 4),
+                                              (COMPUTE_BF16, R.to_torch(sd, round_bf16=True), 0.15, 0.08, 8)):
+        clips, mel_ref = clips_all[:B], mel_all[:B]
+        enc_ref = encode_chunked(mel_ref, W, rd, chunk=4)
+        e = Engine(dims, compute, B)
+        e.load_weights(sd.items())
+        st = e.special
+        e.log_mel(clips, want_output=False)
+        enc = e.encode(B, want_output=True)
+        assert float(np.abs(enc - enc_ref.numpy()).max()) < tol_enc
+        prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+        xkv = R.cross_kv(enc_ref, W, rd)
+        cache = R.SelfCache.empty(rd.dec_layers)
+        e.decode_reset(B)
+        for t in prompt:
+            lg = e.decode_step([t] * B)
+            want = R.decoder_forward(torch.full((B, 1), t), cache, xkv, W, rd)[:, 0].numpy()
+            assert float(np.abs(lg - want).max()) < tol_logit, (compute, t)
+        opts = e.gen_opts(n_new, False, check_interval=1)
+        res = e.generate([prompt] * B, opts)
+        rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                        suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=False)
+        if compute == COMPUTE_F32:
+            ref = R.greedy_decode(enc_ref, prompt, W, rd, rules, n_new)
+            assert res.tokens == ref.tokens
+        else:
+            g = teacher_forced(res.tokens, prompt, enc_ref, W, rd, rules, tol=0.15, margin=0.16)
+            assert g.n_clear >= 0.6 * g.n_steps, g
+        e.close()
