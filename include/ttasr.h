@@ -204,7 +204,7 @@ int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_ro
 /* ---- kernel-selection overrides (tests, A/B measurements) ----------------------------------------- */
 /* The release library reads NO environment variable; every deviation from the measured configuration is an explicit call.
  * Keys (value 0 / 1 unless stated; defaults in brackets): "flash" [1] MFMA flash attention in the encoder (0: the
- * one-query-per-wave f32 kernel); "prefill" [1] batched prompt prefill (0: prompts token by token); "xsplit" [1] frame-split
+ * one-query-per-wave f32 kernel); "prefill" [1] batched prompt prefill (0: prompts token by token); "vocab_persistent" [1] persistent vocabulary GEMM; "xsplit" [1] frame-split
  * cross-attention for small batches; "graph" [1] hipGraph replay of the decode step; "generic_kernels" [0] the 64x64 generic
  * GEMM / per-row kernels everywhere; "prefill_tiled" [0]; "prefill_ns_min" [2] (tokens); "enc_residual_epilogue" [0];
  * "enc_gemm" [0] = 1 | 2 | 3 forces one encoder GEMM kernel; "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =

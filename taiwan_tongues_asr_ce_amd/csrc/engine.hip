@@ -95,6 +95,7 @@ struct ttasr_ctx {
   float* slab = nullptr;      // [16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
   int ks_want[4] = {0, 0, 0, 0};  // option ksplit_out / _q / _qkv / _fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
   int gemm_force = 0;         // option enc_gemm = 1|2|3 (A/B testing of the encoder GEMM kernels)
+  bool vocab_persistent = true;  // option vocab_persistent = 0: the one-workgroup-per-32-outputs kernel for the vocabulary projection (A/B)
   bool no_flash = false;      // option flash = 0
   int prefill_ns_min = 2;     // option prefill_ns_min: shortest prompt (positions before the last) whose <|startoftranscript|> position is taken
                               // from the prefill pass.  Round 3: 2 (was 16) - the small prefill pass now runs the decode-step launch plan
@@ -415,7 +416,13 @@ template <typename T>
 void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
   if (c->skip_mask & 2) return;
   if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && Wsh && launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
+    if (!c->force_basic && Wsh) {
+      // the vocabulary projection (f32 logits, nothing else in the epilogue): persistent workgroups, activation rows in registers
+      const GemmEpi& e = g.epi;
+      if (c->vocab_persistent && e.out_f32 && !e.out_t && !e.bias && !e.residual && e.act == 0 &&
+          launch_gemm_vocab<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, e.out_f32, e.ldc, c->cur)) return;
+      if (launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
+    }
   }
   launch_gemm_basic<T>(g, c->cur);
 }
@@ -857,6 +864,7 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   if (key == "enc_kernel_timing") { c->enc_timing = on; return 0; }   // measurement only: the captured decode graphs stay
   if (key == "flash") c->no_flash = !on;
   else if (key == "prefill") c->no_prefill = !on;
+  else if (key == "vocab_persistent") c->vocab_persistent = on;
   else if (key == "xsplit") c->no_xsplit = !on;
   else if (key == "graph") c->use_graph = on;
   else if (key == "generic_kernels") c->force_basic = on;

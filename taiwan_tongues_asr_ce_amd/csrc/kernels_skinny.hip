@@ -211,6 +211,130 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Vocabulary projection (round 3): logits[b][n] = sum_k x[b][k] * E[n][k], N = 51 866, K = d <= 1280, B <= 64 rows.
+// The generic kernel above launches one workgroup per 32 outputs - 1 621 workgroups that EACH re-read the 82 KB of
+// activation rows for their 82 KB of weights (40 us per step against 21 us for the 133 MB of weights alone).  Here a workgroup
+// is PERSISTENT: 8 waves split K exactly as above (wave w owns k-steps [w * steps, (w + 1) * steps)), each wave loads its slice
+// of the activation rows ONCE into registers (steps * RB * 4 VGPRs) and then walks n-blocks blockIdx.x, + gridDim.x, ... with
+// the NEXT block's weight fragments in flight while the current block's MFMAs and the 8-wave LDS reduction run (two LDS
+// buffers: one barrier per n-block).  Same per-wave accumulation order and the same fixed-order 8-wave sum as the generic
+// kernel with NW = 8: the logits are bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+template <typename T16, int RB, bool NT>
+__global__ __launch_bounds__(512) void gemm_vocab_kernel(const bf16_t* __restrict__ Wsh_, const bf16_t* __restrict__ x_, int B_, int N_,
+                                                         int K_, int steps_, float* __restrict__ out_, int64_t ldc_) {
+  constexpr int NW = 8, U = 10;
+  extern __shared__ __attribute__((aligned(16))) float vred[];   // [2][NW][RB][32 * 32]
+  const bf16_t* Wsh = sgpr_pin_ptr(Wsh_);
+  const bf16_t* x = sgpr_pin_ptr(x_);
+  const int B = sgpr_pin(B_), N = sgpr_pin(N_), K = sgpr_pin(K_), steps = sgpr_pin(steps_);
+  float* out = sgpr_pin_ptr(out_);
+  const int64_t ldc = sgpr_pin(ldc_);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ks_per = K / 16, n_blocks = (N + 31) / 32;
+  const int k0 = wave * steps;
+  const u32x4* wbase = (const u32x4*)Wsh + (int64_t)k0 * 64 + lane;
+  auto load_w = [&](int nb, u32x4 (&w)[U]) {
+    const u32x4* wp = wbase + (int64_t)min(nb, n_blocks - 1) * ks_per * 64;   // clamped: the last prefetch re-reads a valid block
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(u, steps - 1);
+      if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64); else w[u] = wp[(int64_t)i * 64];
+    }
+  };
+  int nb = blockIdx.x;
+  u32x4 wa[U], wb[U];
+  load_w(nb, wa);                                 // the weight stream starts before the activation rows are fetched
+  u32x4 xv[RB][U];
+#pragma unroll
+  for (int g = 0; g < RB; ++g) {
+    const bf16_t* xp = x + (int64_t)min(g * 32 + (lane & 31), B - 1) * K + k0 * 16 + 8 * (lane >> 5);
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[g][u] = *(const u32x4*)(xp + min(u, steps - 1) * 16);
+  }
+  int par = 0;
+  auto block = [&](int nb_cur, u32x4 (&wc)[U], u32x4 (&wn)[U]) {
+    load_w(nb_cur + gridDim.x, wn);               // next block's fragments: in flight under this block's MFMAs + reduction
+    f32x16 acc[RB];
+#pragma unroll
+    for (int g = 0; g < RB; ++g)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[g][j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < steps) {
+#pragma unroll
+        for (int g = 0; g < RB; ++g) acc[g] = N16<T16>::mfma32(*(s16x8*)&wc[u], *(s16x8*)&xv[g][u], acc[g]);
+      }
+    float* red = vred + (size_t)par * NW * RB * 1024;
+#pragma unroll
+    for (int g = 0; g < RB; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(float4*)&red[(wave * RB + g) * 1024 + (lane & 31) * 32 + 8 * q + 4 * (lane >> 5)] =
+            make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
+    __syncthreads();   // one barrier per block: the other LDS buffer is only rewritten after the NEXT barrier
+    if (tid < 256) {
+      const int en = nb_cur * 32 + 4 * (tid & 7);
+#pragma unroll
+      for (int g = 0; g < RB; ++g) {
+        float4 v = *(const float4*)&red[(0 * RB + g) * 1024 + (tid >> 3) * 32 + 4 * (tid & 7)];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+          const float4 t = *(const float4*)&red[(w * RB + g) * 1024 + (tid >> 3) * 32 + 4 * (tid & 7)];
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int b = g * 32 + (tid >> 3);
+        if (b < B) {
+          float* o = out + (int64_t)b * ldc + en;
+          if (en + 3 < N) *(float4*)o = v;
+          else { const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (en + j < N) o[j] = vv[j]; }
+        }
+      }
+    }
+    par ^= 1;
+  };
+  // two blocks per trip so that the register sets alternate with static names (a runtime-indexed array would go to scratch)
+  while (nb < n_blocks) {
+    block(nb, wa, wb);
+    nb += gridDim.x;
+    if (nb >= n_blocks) break;
+    block(nb, wb, wa);
+    nb += gridDim.x;
+  }
+}
+
+// Returns false when the shape does not fit (caller falls back to launch_gemm_skinny).
+template <typename T16>
+bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s) {
+  if (B < 1 || B > 64 || K % 128 != 0 || K / 128 > 10 || N < 8192 || ldc % 4 != 0) return false;
+  const int rb = (B + 31) / 32, steps = K / 128, n_blocks = (N + 31) / 32;
+  static int n_cu = 0;
+  if (!n_cu) { hipDeviceProp_t p; int dev = 0; hipGetDevice(&dev); n_cu = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }
+  const int grid = n_blocks < n_cu ? n_blocks : n_cu;
+  const size_t lds = (size_t)2 * 8 * rb * 1024 * sizeof(float);   // 64 KiB per row group
+#define TTASR_VOCAB(RB_)                                                                                                           \
+  do {                                                                                                                             \
+    static bool attr[2][64] = {{false}};                                                                                           \
+    int dev = 0; hipGetDevice(&dev);                                                                                               \
+    if (!attr[g_skinny_nt ? 1 : 0][dev & 63]) {                                                                                    \
+      hipFuncSetAttribute((const void*)gemm_vocab_kernel<T16, RB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+      hipFuncSetAttribute((const void*)gemm_vocab_kernel<T16, RB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+      attr[0][dev & 63] = attr[1][dev & 63] = true;                                                                                \
+    }                                                                                                                              \
+    if (g_skinny_nt) hipLaunchKernelGGL((gemm_vocab_kernel<T16, RB_, true>), dim3(grid), dim3(512), lds, s, (const bf16_t*)Wsh, (const bf16_t*)x, B, N, K, steps, out, ldc); \
+    else hipLaunchKernelGGL((gemm_vocab_kernel<T16, RB_, false>), dim3(grid), dim3(512), lds, s, (const bf16_t*)Wsh, (const bf16_t*)x, B, N, K, steps, out, ldc); \
+  } while (0)
+  if (rb == 1) TTASR_VOCAB(1); else TTASR_VOCAB(2);
+#undef TTASR_VOCAB
+  return true;
+}
+template bool launch_gemm_vocab<bf16_t>(const bf16_t*, const bf16_t*, int, int, int, float*, int64_t, hipStream_t);
+template bool launch_gemm_vocab<f16_t>(const f16_t*, const f16_t*, int, int, int, float*, int64_t, hipStream_t);
+
 // K slices a split decode GEMM is cut into (1 = unsplit).  `want` = requested slice count (0 = automatic: weights in
 // pieces of <= ~20 KB per workgroup, a few hundred workgroups); the result divides the k-steps evenly over 4 waves.
 int gemm_skinny_ksplit(int B, int N, int K, int want) {

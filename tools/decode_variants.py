@@ -27,10 +27,11 @@ VARIANTS = {
     "f16": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 16},
     "f10": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 10},
     "qkv4": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 4, "ksplit_fc2": 8},
+    "vocab_generic": {"vocab_persistent": 0},             # round-2 vocabulary GEMM: one workgroup per 32 outputs
     "w_plain": {"weights_nontemporal": 0},
     "xattn_plain": {"xattn_nontemporal": 0},
 }
-DEFAULTS = {"prefill_ns_min": 2, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
+DEFAULTS = {"vocab_persistent": 1, "prefill_ns_min": 2, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
             "xattn_nontemporal": 1}
 
 
