@@ -216,7 +216,7 @@ def test_full_depth_bf16_against_oracle_with_rounded_weights(oracle_full):
             n_clear += 1
         assert s[t] > -np.inf and float(s.max() - s[t]) < 0.15, i
         logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, rd)[:, 0]
-    assert n_clear >= 1
+    assert n_clear >= 4, n_clear      # at least half of the 8 steps were held to token equality (measured: 7-8)
 
 
 def test_full_depth_beam5_eight_clips_properties_and_oracle_scores(oracle_full):

@@ -68,14 +68,11 @@ def test_width_parity_f32_and_bf16(dims):
     for t, lg in zip(prompt, step_logits_b):
         logits = R.decoder_forward(torch.full((2, 1), t), cache, xkv, Wb, rd)[:, 0]
         assert np.abs(lg - logits.numpy()).max() < 0.08
-    for i in range(min(len(t) for t in res_b.tokens)):
-        nxt = []
-        for b in range(2):
-            s = R.apply_rules(logits[b], res_b.tokens[b][:i], rules)
-            c = res_b.tokens[b][i]
-            assert float(s.max() - s[c]) < 0.15
-            nxt.append(c)
-        logits = R.decoder_forward(torch.tensor(nxt)[:, None], cache, xkv, Wb, rd)[:, 0]
+    # teacher-forced on the engine's tokens: every choice within 0.15 of the oracle's best allowed logit AND equal to the oracle's
+    # token wherever its top-2 margin exceeds 0.16 (2 x the logit tolerance); most steps carry such a margin
+    from oracle_checks import teacher_forced
+    g = teacher_forced(res_b.tokens, prompt, enc_rb, Wb, rd, rules, tol=0.15, margin=0.16)
+    assert g.n_steps >= 2 * 4 and g.n_clear >= 0.6 * g.n_steps, g
 
 
 @pytest.mark.gpu

@@ -383,3 +383,45 @@ def test_concurrent_calls_on_one_context_are_refused(eng_tiny_f32):
     assert out["tokens"] == ref                       # the call in flight was not disturbed
     assert len(errors) > 0                            # at least one intruding call was refused
     e._check(e.lib.ttasr_sync(e.h), "sync")           # and the context works normally afterwards
+
+
+def test_set_option_variants_stay_within_tolerance_and_bad_keys_are_refused(tiny_oracle):
+    """ttasr_set_option is the only way to leave the measured kernel selection (the library reads no environment variable).
+    Every override must still be a CORRECT engine: the bf16 greedy tokens of each variant pass the same oracle grading as the
+    default (within 0.15 of the oracle's best, equal to its token at margins > 0.3), replays stay bit-identical, and switching
+    an option back restores the default's exact tokens.  Unknown keys / out-of-range values return an error."""
+    from oracle_checks import teacher_forced
+    dims, _, clips, _ = tiny_oracle
+    Wb = R.to_torch(synth.state_dict(PRESETS["tiny"]), round_bf16=True)
+    enc_ref = R.encoder_forward(torch.from_numpy(np.stack([R.log_mel(c, 80) for c in clips])), Wb, dims)
+    e = _engine("tiny", COMPUTE_BF16, 4)
+    st = e.special
+    prompt = [st.sot_prev, 1000, 1001, 1002, 1003, st.sot, st.lang_zh, st.transcribe]       # long enough for the prefill pass
+    opts = e.gen_opts(12, True, sot_index=5)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=True)
+
+    def run():
+        e.log_mel(clips, want_output=False)
+        e.encode(4)
+        a = e.generate([prompt] * 4, opts)
+        b = e.generate([prompt] * 4, opts)
+        assert a.tokens == b.tokens and np.array_equal(a.sum_logprob, b.sum_logprob)
+        g = teacher_forced(a.tokens, prompt, enc_ref, Wb, dims, rules, tol=0.15, margin=0.3)
+        assert g.n_steps >= 4 * 6
+        return a.tokens
+    base = run()
+    for key, val in (("graph", 0), ("prefill", 0), ("xsplit", 0), ("flash", 0), ("vocab_persistent", 0), ("prefill_tiled", 1),
+                     ("ksplit_out", 2), ("ksplit_fc2", 4), ("ksplit_qkv", 1), ("weights_nontemporal", 0), ("xattn_nontemporal", 0),
+                     ("enc_gemm", 2), ("enc_residual_epilogue", 1), ("generic_kernels", 1)):
+        e.set_option(key, val)
+        run()
+        default = {"graph": 1, "prefill": 1, "xsplit": 1, "flash": 1, "vocab_persistent": 1, "prefill_tiled": 0, "ksplit_out": 0,
+                   "ksplit_fc2": 0, "ksplit_qkv": 0, "weights_nontemporal": 1, "xattn_nontemporal": 1, "enc_gemm": 0,
+                   "enc_residual_epilogue": 0, "generic_kernels": 0}[key]
+        e.set_option(key, default)
+    assert run() == base                                        # every option restored: the default engine again, bit for bit
+    for key, val in (("no_such_option", 1), ("enc_gemm", 7), ("ksplit_q", 99), ("prefill_ns_min", -1)):
+        assert e.lib.ttasr_set_option(e.h, key.encode(), val) == -1
+        assert b"option" in e.lib.ttasr_last_error(e.h)
+    e.close()
