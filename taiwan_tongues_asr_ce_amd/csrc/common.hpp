@@ -214,7 +214,8 @@ bool launch_gemm_skinny(const T16* Wsh, const T16* x, int B, int N, int K, const
                         float* slab = nullptr, int64_t slab_stride = 0);
 int gemm_skinny_ksplit(int B, int N, int K, int want);
 // vocabulary projection: persistent workgroups that keep the activation rows in registers (kernels_skinny.hip); false: shape unsupported
-template <typename T16> bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s);
+template <typename T16> bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s, int device);
+void gemm_vocab_init(int device);   // once per device, outside any stream capture (ttasr_create)
 // mel
 // geom_dev (optional): int64 [B][3] = {lead, reflect_end, valid_frames} per clip - window-of-a-file geometry, kernels_misc.hip
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,

@@ -420,7 +420,7 @@ void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
       // the vocabulary projection (f32 logits, nothing else in the epilogue): persistent workgroups, activation rows in registers
       const GemmEpi& e = g.epi;
       if (c->vocab_persistent && e.out_f32 && !e.out_t && !e.bias && !e.residual && e.act == 0 &&
-          launch_gemm_vocab<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, e.out_f32, e.ldc, c->cur)) return;
+          launch_gemm_vocab<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, e.out_f32, e.ldc, c->cur, c->device)) return;
       if (launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
     }
   }
@@ -551,8 +551,10 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   auto slices = [&](int kind, int N, int K) {
     if (!skinny) return 1;
     int want = c->ks_want[kind];
-    // qkv (N = 3 d: already 3x the workgroups of the other GEMMs): 2 slices measured best (5.35 vs 6.02 us at large-v3)
-    if (kind == 2 && want == 0 && (N + 31) / 32 >= 96) want = 2;
+    // qkv (N = 3 d: already 3x the workgroups of the other GEMMs): 2 slices measured best (5.35 vs 6.02 us at large-v3) - with ONE
+    // 32-row group; wider batches (beam search, streaming: 33-128 rows) keep the automatic choice, whose k-steps per wave fit the
+    // straight-line form (2 slices there meant the looped form: 10.4 us at 40 rows)
+    if (kind == 2 && want == 0 && n <= 32 && (N + 31) / 32 >= 96) want = 2;
     int ks = gemm_skinny_ksplit(n, N, K, want);
     if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
     return ks;
@@ -964,6 +966,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
   p->cur = p->stream;
+  gemm_vocab_init(device_id);
   {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
     const size_t d = p->d, ffn = p->ffn, T = p->T, B = p->maxB;
     const size_t w = ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);

@@ -307,24 +307,30 @@ __global__ __launch_bounds__(512) void gemm_vocab_kernel(const bf16_t* __restric
   }
 }
 
+// Per-device set-up, called from ttasr_create (NOT lazily from the launcher: the first launch of a shape happens inside a
+// hipGraph stream capture, where attribute / property calls do not belong - under rocprofv3 they crashed the capture): the
+// opt-in to > 64 KiB of dynamic LDS for every instantiation and the CU count that sizes the persistent grid.
+static int g_vocab_cus[64] = {0};
+void gemm_vocab_init(int device) {
+  hipDeviceProp_t p;
+  g_vocab_cus[device & 63] = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
+#define TTASR_VOCAB_ATTR(T_, RB_)                                                                                                          \
+  hipFuncSetAttribute((const void*)gemm_vocab_kernel<T_, RB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * RB_ * 4096);     \
+  hipFuncSetAttribute((const void*)gemm_vocab_kernel<T_, RB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * RB_ * 4096)
+  TTASR_VOCAB_ATTR(bf16_t, 1); TTASR_VOCAB_ATTR(bf16_t, 2); TTASR_VOCAB_ATTR(f16_t, 1); TTASR_VOCAB_ATTR(f16_t, 2);
+#undef TTASR_VOCAB_ATTR
+}
+
 // Returns false when the shape does not fit (caller falls back to launch_gemm_skinny).
 template <typename T16>
-bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s) {
-  if (B < 1 || B > 64 || K % 128 != 0 || K / 128 > 10 || N < 8192 || ldc % 4 != 0) return false;
+bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s, int device) {
+  const int n_cu = g_vocab_cus[device & 63];
+  if (n_cu <= 0 || B < 1 || B > 64 || K % 128 != 0 || K / 128 > 10 || N < 8192 || ldc % 4 != 0) return false;
   const int rb = (B + 31) / 32, steps = K / 128, n_blocks = (N + 31) / 32;
-  static int n_cu = 0;
-  if (!n_cu) { hipDeviceProp_t p; int dev = 0; hipGetDevice(&dev); n_cu = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }
   const int grid = n_blocks < n_cu ? n_blocks : n_cu;
   const size_t lds = (size_t)2 * 8 * rb * 1024 * sizeof(float);   // 64 KiB per row group
 #define TTASR_VOCAB(RB_)                                                                                                           \
   do {                                                                                                                             \
-    static bool attr[2][64] = {{false}};                                                                                           \
-    int dev = 0; hipGetDevice(&dev);                                                                                               \
-    if (!attr[g_skinny_nt ? 1 : 0][dev & 63]) {                                                                                    \
-      hipFuncSetAttribute((const void*)gemm_vocab_kernel<T16, RB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-      hipFuncSetAttribute((const void*)gemm_vocab_kernel<T16, RB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-      attr[0][dev & 63] = attr[1][dev & 63] = true;                                                                                \
-    }                                                                                                                              \
     if (g_skinny_nt) hipLaunchKernelGGL((gemm_vocab_kernel<T16, RB_, true>), dim3(grid), dim3(512), lds, s, (const bf16_t*)Wsh, (const bf16_t*)x, B, N, K, steps, out, ldc); \
     else hipLaunchKernelGGL((gemm_vocab_kernel<T16, RB_, false>), dim3(grid), dim3(512), lds, s, (const bf16_t*)Wsh, (const bf16_t*)x, B, N, K, steps, out, ldc); \
   } while (0)
@@ -332,8 +338,8 @@ bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float*
 #undef TTASR_VOCAB
   return true;
 }
-template bool launch_gemm_vocab<bf16_t>(const bf16_t*, const bf16_t*, int, int, int, float*, int64_t, hipStream_t);
-template bool launch_gemm_vocab<f16_t>(const f16_t*, const f16_t*, int, int, int, float*, int64_t, hipStream_t);
+template bool launch_gemm_vocab<bf16_t>(const bf16_t*, const bf16_t*, int, int, int, float*, int64_t, hipStream_t, int);
+template bool launch_gemm_vocab<f16_t>(const f16_t*, const f16_t*, int, int, int, float*, int64_t, hipStream_t, int);
 
 // K slices a split decode GEMM is cut into (1 = unsplit).  `want` = requested slice count (0 = automatic: weights in
 // pieces of <= ~20 KB per workgroup, a few hundred workgroups); the result divides the k-steps evenly over 4 waves.
@@ -400,9 +406,11 @@ bool launch_gemm_skinny(const T16* Wsh_, const T16* x_, int B, int N, int K, con
   if (rb == 1) {
     if (nw == 16) TTASR_SKINNY_U(16, 1, 10); else if (nw == 8) TTASR_SKINNY_U(8, 1, 10); else TTASR_SKINNY_U(4, 1, 10);
   } else if (rb == 2) {
-    if (nw == 8) TTASR_SKINNY_U(8, 2, 8); else TTASR_SKINNY_U(4, 2, 8);
+    // 8-wave workgroups run 2 waves per SIMD (256 VGPRs each): the unsplit K = 1280 GEMMs (fc1, qkv of a prefill pass: 10 k-steps
+    // per wave) keep all 10 in flight in the straight-line form - the looped form cost 13.2 us against 5.4 us at one row group
+    if (nw == 8) TTASR_SKINNY_U(8, 2, 10); else TTASR_SKINNY_U(4, 2, 8);
   } else if (rb == 3) {
-    if (nw == 8) TTASR_SKINNY_U(8, 3, 5); else TTASR_SKINNY_U(4, 3, 5);
+    if (nw == 8) TTASR_SKINNY_U(8, 3, 10); else TTASR_SKINNY_U(4, 3, 5);
   } else {
     if (nw == 8) TTASR_SKINNY_U(8, 4, 5); else TTASR_SKINNY_U(4, 4, 5);
   }
