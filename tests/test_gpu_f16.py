@@ -189,3 +189,9 @@ def test_f16_device_intake_and_facade():
     assert m.engine.compute_type == COMPUTE_F16
     segs, info = m.transcribe(synth.noise_clip(3, 160000), language="zh", beam_size=5, vad_filter=False)
     assert info.language == "zh" and isinstance(list(segs), list)
+    # the alignment pass (word timestamps: cross-attention rows of the alignment heads + token log-probs) in fp16
+    segs, _ = m.transcribe(synth.tonal_clip(4, 160000), language="zh", beam_size=1, vad_filter=False, word_timestamps=True,
+                           temperature=0.0, max_new_tokens=24)
+    words = [w for s_ in segs for w in (s_.words or [])]
+    assert all(0.0 <= w.start <= w.end <= 10.0 + 1e-3 and 0.0 <= w.probability <= 1.0 for w in words)
+    assert all(a.start <= b.start + 1e-6 for a, b in zip(words, words[1:]))
