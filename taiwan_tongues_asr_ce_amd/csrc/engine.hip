@@ -928,7 +928,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
 
 extern "C" {
 
-const char* ttasr_version(void) { return "ttasr 0.1 (gfx950, HIP)"; }
+const char* ttasr_version(void) { return "ttasr 0.3 (gfx950, HIP; f32 | bf16 | fp16)"; }
 
 const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
