@@ -318,3 +318,15 @@ def test_adapter_retries_without_vad_only_when_a_vad_source_is_configured():
         out = asyncio.run(a.transcribe(client))
         assert a.asr_pipeline.calls == want_calls
         assert (out["text"] if out else None) == want_text
+
+
+def test_every_set_option_key_is_documented_in_the_header():
+    """include/ttasr.h lists the ttasr_set_option keys; the list must be exactly what the library accepts (engine.hip)."""
+    src = open(os.path.join(ROOT, "taiwan_tongues_asr_ce_amd", "csrc", "engine.hip")).read()
+    body = src[src.index("int set_option(ttasr_ctx* c, const std::string& key, int v) {"):]
+    body = body[:body.index("\n}\n")]
+    accepted = set(re.findall(r'key == "([a-z_0-9]+)"', body))
+    hdr = open(os.path.join(ROOT, "include", "ttasr.h")).read()
+    doc = hdr[hdr.index("kernel-selection overrides"):hdr.index("int ttasr_set_option")]
+    documented = set(re.findall(r'"([a-z_0-9]+)"', doc))
+    assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
