@@ -183,9 +183,34 @@ def _self_launch(n: int) -> int:
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    for line in out0.splitlines():      # rank 0 prints the ONE JSON line; library chatter on its stdout is not relayed
+    # rank 0's stdout is drained on a thread so that the parent can watch every child: when ANY rank dies, the others - which
+    # would otherwise sit in a collective until its timeout - are ended (by their exact PIDs) and the launch fails at once
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(p.wait())
+    rd.join(5)
+    if failed is not None:
+        print(f"bench.py --gpus {n}: rank {failed[0]} exited with code {failed[1]}; the other ranks were stopped", file=sys.stderr, flush=True)
+        return abs(failed[1]) or 1
+    for line in (out0[0].decode() if out0 else "").splitlines():   # rank 0 prints the ONE JSON line; library chatter is not relayed
         if line.startswith("{"):
             print(line, flush=True)
     return max(abs(rc) for rc in rcs)
@@ -334,8 +359,13 @@ def main():
     if grp:
         dist_barrier(local)
     dt = time.perf_counter() - t0
+    rank_ms = None
     if grp:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else f"cuda:{local}")
+        cdev = "cpu" if dist.get_backend() == "gloo" else f"cuda:{local}"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                         # every rank's own clock around its K steps
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert toks.shape == (world * B * C_, args.new_tokens)
@@ -494,7 +524,10 @@ def main():
                        "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else "") +
                                       (" (ranks share GPUs over gloo: plumbing check, not a scaling number)"
                                        if world > torch.cuda.device_count() else ""),
-                       "rank_logits_spread": logits_spread, "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
+                       "rank_logits_spread": logits_spread,
+                       "rank_ms_per_step": None if rank_ms is None else {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2),
+                                                                          "per_rank": [round(x, 2) for x in rank_ms]},
+                       "phase_ms": ph, "median_ms_per_step": round(float(np.median(per_step)) * 1e3, 2),
                        "host_pcm_ms_per_step": round(host_ms, 2), "weight_load_s": round(t_load, 1)},
             "roofline": roof,
             "mfma": {"kernel": "encoder layer GEMMs (qkv, out-proj, fc1, fc2; flop-weighted), timed IN SITU: one pass of the real "
@@ -561,6 +594,9 @@ def main():
             out["more_in_flight"] = {"contexts_per_gpu": 2, "clips_in_flight_per_gpu": 2 * B, "steps": n2,
                                      "audio_s_per_s": round(2 * B * 30.0 * n2 / t2, 2),
                                      "note": "side measurement; the headline value above is one context, one batch in flight"}
+        if world > 1:   # a multi-rank line must say how the ranks talked and prove they hold the same weights
+            assert transport is not None and logits_spread is not None and rank_ms is not None and len(rank_ms) == world, \
+                (transport, logits_spread, rank_ms)
         print(json.dumps(out), flush=True)
     for e_ in engines:
         e_.close()

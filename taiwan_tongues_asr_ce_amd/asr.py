@@ -17,14 +17,6 @@ class ASRInterface:
     async def transcribe(self, client):
         raise NotImplementedError("This method should be implemented by subclasses.")
 
-    def _vad_is_active(self) -> bool:
-        """True when vad_filter=True really filters: the operator supplied a speech-probability source on the model, or the
-        default kwargs opt into the energy stand-in."""
-        if getattr(self.asr_pipeline, "vad_speech_prob_fn", None) is not None:
-            return True
-        params = self.default_transcribe_kwargs.get("vad_parameters") or {}
-        return params.get("backend") == "energy"
-
     def warm_up(self):
         raise NotImplementedError("This method should be implemented by subclasses.")
 
@@ -53,6 +45,17 @@ class MI355XWhisperASR(ASRInterface):
             "initial_prompt": "繁體中文",
         }
         self.text_filter = kwargs.get("text_filter")  # utils.filter_text of the reference, injected by the caller
+        # faster_whisper_asr.py:186-198 retries an empty VAD-filtered result without VAD - but it re-opens a temp file it deleted
+        # at :179, always lands in its `except: pass` and returns None.  The EFFECTIVE reference behaviour (None for a chunk the
+        # VAD empties: the commonest streaming case is an all-silence chunk, on which Whisper hallucinates) is the default here;
+        # the retry the reference's author intended is an explicit opt-in, and its result is still dropped when the decoder
+        # itself calls the chunk silence (no_speech_prob) or is unsure of it (avg_logprob).
+        self.retry_without_vad = bool(kwargs.get("retry_without_vad", False))
+        self.retry_no_speech_threshold = float(kwargs.get("retry_no_speech_threshold", 0.6))
+        self.retry_logprob_threshold = float(kwargs.get("retry_logprob_threshold", -1.0))
+        fn = kwargs.get("vad_speech_prob_fn")
+        if fn is not None:   # a speech-probability source handed to the adapter lands on the model (model.vad_speech_prob_fn)
+            self.asr_pipeline.vad_speech_prob_fn = fn
 
     async def transcribe(self, client) -> Optional[Dict[str, Any]]:
         try:
@@ -66,15 +69,15 @@ class MI355XWhisperASR(ASRInterface):
                 warnings.filterwarnings("ignore", message="vad_filter=True")
                 segments, info = self.asr_pipeline.transcribe(audio, **kw)
                 segments = list(segments)
-                if len(segments) == 0 and kw.get("vad_filter") and self._vad_is_active():
-                    # faster_whisper_asr.py:186-196: nothing came back with VAD on -> once more with VAD off, so that an
-                    # over-eager filter cannot swallow a whole utterance.  (The reference re-reads a temp file it has
-                    # already deleted at :179 and so always falls into its `except: pass`; here the audio is still in hand.)
-                    # Only when a VAD source is configured: without one vad_filter=True already kept the whole clip.
+                if len(segments) == 0 and self.retry_without_vad and kw.get("vad_filter") and self._vad_is_active():
+                    # opt-in only (see __init__): once more with VAD off, so that an over-eager filter cannot swallow a whole
+                    # utterance; segments the decoder itself marks as silence or as a low-confidence guess are dropped
                     try:
                         retry = dict(kw, vad_filter=False)
                         segments, info = self.asr_pipeline.transcribe(audio, **retry)
-                        segments = list(segments)
+                        segments = [s for s in segments
+                                    if not (getattr(s, "no_speech_prob", 0.0) > self.retry_no_speech_threshold
+                                            or getattr(s, "avg_logprob", 0.0) < self.retry_logprob_threshold)]
                     except Exception as e:      # the reference swallows a failing retry too (:197-198)
                         logger.debug("retry without VAD failed: %s", e)
                         segments = []
@@ -102,6 +105,8 @@ class MI355XWhisperASR(ASRInterface):
         """True when vad_filter=True really filters: the operator supplied a speech-probability source on the model, or the
         default kwargs opt into the energy stand-in."""
         if getattr(self.asr_pipeline, "vad_speech_prob_fn", None) is not None:
+            return True
+        if self.default_transcribe_kwargs.get("vad_speech_prob_fn") is not None:
             return True
         params = self.default_transcribe_kwargs.get("vad_parameters") or {}
         return params.get("backend") == "energy"

@@ -42,11 +42,15 @@ template <> struct N16<f16_t> {
     const h16x2_hw v = __builtin_bit_cast(h16x2_hw, w);
     lo = (float)v[0]; hi = (float)v[1];
   }
+  // Saturating: |v| > 65504 would become inf and turn into NaN in the next LayerNorm / softmax; HF clamps its
+  // fp16 hidden states for the same reason (modeling_whisper.py:403-407).  A NaN stays a NaN (fmaxf / fminf alone would turn
+  // it into a finite number and hide an upstream fault).
+  static __device__ __forceinline__ float sat(float v) { return v != v ? v : __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
   static __device__ __forceinline__ uint32_t pk(float lo, float hi) {   // round-to-nearest-even, one v_cvt_pk_f16_f32
     typedef float f32x2_hw __attribute__((ext_vector_type(2)));
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){lo, hi}, h16x2_hw));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){sat(lo), sat(hi)}, h16x2_hw));
   }
-  static __device__ __forceinline__ uint16_t down(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+  static __device__ __forceinline__ uint16_t down(float f) { return __builtin_bit_cast(uint16_t, (_Float16)sat(f)); }
   static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
   }
@@ -289,8 +293,11 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
                               SlabIn sq = SlabIn{} /*q from K-split partial tiles*/,
                               int ws_rows = 0 /*rows the workspace was sized for (0: B); rows that share a clip (kv_div 2..8)
                                                 are served by one K/V stream per clip when they fit*/);
-extern int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs (A/B experiments)
-extern int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant (A/B experiments)
+// Kernel-variant switches of the launchers (A/B experiments).  Thread-local: every C-ABI call copies its CONTEXT's setting in
+// before it launches anything (engine.hip guarded()), so an option set on one context never changes what another context's
+// thread launches or what its captured graphs hold.
+extern thread_local int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs
+extern thread_local int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the
 // per-row history state uploaded by the host)
 struct BeamRowState { const int32_t *n_sampled, *last_tok, *pen_tok, *last_ts; const uint8_t* mask; };

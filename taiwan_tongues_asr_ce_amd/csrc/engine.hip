@@ -108,6 +108,7 @@ struct ttasr_ctx {
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
+  int xattn_nt = 1, weights_nt = 1;  // options xattn_nontemporal / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
   bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)
   bool prefill_tiled = false;  // option prefill_tiled: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
@@ -122,7 +123,8 @@ struct ttasr_ctx {
 
   // decode-step graphs keyed by (B, with_logits)
   struct GraphKey { int B; int mode; int variant; hipGraphExec_t exec; };
-  std::vector<GraphKey> graphs;
+  std::vector<GraphKey> graphs;   // least recently used first
+  static constexpr size_t kMaxGraphs = 16;
   RuleParams rp{};
 };
 
@@ -782,15 +784,26 @@ int step_graph(ttasr_ctx* c, int B, int mode) {
     return 0;
   }
   const int variant = c->kv_div * 2 + c->identity_pages;
-  for (auto& g : c->graphs)
-    if (g.B == B && g.mode == mode && g.variant == variant) { HIPCHK(c, hipGraphLaunch(g.exec, c->stream)); return 0; }
-  hipGraph_t graph;
+  for (size_t i = 0; i < c->graphs.size(); ++i) {
+    if (c->graphs[i].B == B && c->graphs[i].mode == mode && c->graphs[i].variant == variant) {
+      // most recently used at the back: the cache is bounded (the streaming micro-batcher varies B from 1 to max_batch rows)
+      if (i + 1 != c->graphs.size()) std::rotate(c->graphs.begin() + i, c->graphs.begin() + i + 1, c->graphs.end());
+      HIPCHK(c, hipGraphLaunch(c->graphs.back().exec, c->stream));
+      return 0;
+    }
+  }
+  hipGraph_t graph = nullptr;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
   HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
-  hipGraphExec_t exec;
-  HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-  hipGraphDestroy(graph);
+  hipGraphExec_t exec = nullptr;
+  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);   // on the failure path too
+  if (ie != hipSuccess) return fail(c, TTASR_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+  if (c->graphs.size() >= ttasr_ctx::kMaxGraphs) {   // evict the least recently used executable
+    hipGraphExecDestroy(c->graphs.front().exec);
+    c->graphs.erase(c->graphs.begin());
+  }
   c->graphs.push_back({B, mode, variant, exec});
   HIPCHK(c, hipGraphLaunch(exec, c->stream));
   return 0;
@@ -878,8 +891,8 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   else if (key == "ksplit_q") { if (v < 0 || v > 16) return 1; c->ks_want[1] = v; }
   else if (key == "ksplit_qkv") { if (v < 0 || v > 16) return 1; c->ks_want[2] = v; }
   else if (key == "ksplit_fc2") { if (v < 0 || v > 16) return 1; c->ks_want[3] = v; }
-  else if (key == "xattn_nontemporal") g_xattn_variant = on ? 1 : 0;   // process-wide (kernel template choice)
-  else if (key == "weights_nontemporal") g_skinny_nt = on ? 1 : 0;     // process-wide
+  else if (key == "xattn_nontemporal") g_xattn_variant = c->xattn_nt = on ? 1 : 0;   // per context (kernel template choice)
+  else if (key == "weights_nontemporal") g_skinny_nt = c->weights_nt = on ? 1 : 0;
   else return 1;
   drop_graphs(c);
   return 0;
@@ -915,6 +928,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
+  if (c) { g_xattn_variant = c->xattn_nt; g_skinny_nt = c->weights_nt; }   // this context's kernel variants for everything f launches
   try {
     return f();
   } catch (const std::bad_alloc&) {
@@ -1241,6 +1255,9 @@ int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
   if (c->lowp) { HIPCHK(c, hipMemcpyAsync(c->x, enc, n * 4, hipMemcpyHostToDevice, c->stream));
                  TT_DISPATCH(c, launch_cast<T>(c->x, (T*)c->enc_out, n, c->stream)); }
   else HIPCHK(c, hipMemcpyAsync(c->enc_out, enc, n * 4, hipMemcpyHostToDevice, c->stream));
+  c->cur = c->stream;
+  c->enc_ev_class.clear();   // in-situ timing marks belong to ONE pass: start a fresh list (they used to pile up here)
+  enc_mark(c, -1);
   TT_DISPATCH(c, run_cross_kv<T>(c, B));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());

@@ -153,7 +153,7 @@ template <> __device__ __forceinline__ void store_row<f16_t>(f16_t* p, const flo
 // over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
-int g_xattn_variant = 1;  // option xattn_nontemporal; default 1 = nontemporal K/V loads
+thread_local int g_xattn_variant = 1;  // option xattn_nontemporal; default 1 = nontemporal K/V loads
 using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 
 // Single pass, one memory round trip for pos <= 32*UNROLL cached keys: every lane keeps an online-softmax

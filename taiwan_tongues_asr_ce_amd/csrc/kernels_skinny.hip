@@ -62,7 +62,7 @@ template void launch_shuffle_cast<f16_t>(const float*, f16_t*, int, int, int, hi
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
 // which is what amortises the per-step latency when more clips are in flight).
-int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (option weights_nontemporal = 0 switches them off: A/B experiments; the 1.8 GB of decoder weights a step streams can never stay cached: -1 % per step)
+thread_local int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (option weights_nontemporal = 0 switches them off: A/B experiments; the 1.8 GB of decoder weights a step streams can never stay cached: -1 % per step)
 
 // ONE = the wave's k-steps fit one batch of loads (steps <= U): straight-line code.  (As a loop, the register reuse of
 // the next iteration forces an early s_waitcnt that, in the first iteration, waits for the bias / residual prefetch

@@ -30,8 +30,10 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if "MASTER_PORT" not in os.environ:       # forced single-rank group started from a bare shell
-            import socket
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:   # every rank would pick a different free port and the rendezvous would hang until its timeout
+                raise RuntimeError("MASTER_PORT is not set (WORLD_SIZE=%d): launch through torch.distributed.run / bench.py --gpus N" % world)
+            import socket       # forced single-rank group started from a bare shell
             s = socket.socket()
             s.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(s.getsockname()[1])
@@ -44,6 +46,11 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
             local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
             kw["device_id"] = torch.device("cuda", local)   # binds the communicator to this rank's GPU at creation (eager init)
+        # a peer that died must not leave this rank parked in a collective for the backend's default 10-30 min: the group's
+        # timeout ends it (RCCL: the watchdog aborts the process; gloo: the collective raises) - bench.py's launcher and
+        # torch.distributed.run additionally stop the other ranks the moment one exits non-zero
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=int(os.environ.get("TTASR_DIST_TIMEOUT_S", "600")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
@@ -93,8 +100,8 @@ def bucket_plan(sizes: Sequence[int], kinds: Sequence[int], bucket_bytes: int, e
 
 
 def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, np.ndarray]]], device=None,
-                      bucket_bytes: int = 256 << 20, bf16_matrices: bool = False, matrix_dtype: Optional[str] = None
-                      ) -> Iterator[Tuple[str, object]]:
+                      bucket_bytes: int = 256 << 20, bf16_matrices: bool = False, matrix_dtype: Optional[str] = None,
+                      host_16bit: bool = False) -> Iterator[Tuple[str, object]]:
     """Rank 0 supplies (name, array) in tensor_specs order; every rank yields every tensor once (bucket order - the engine's
     intake is keyed by name).  Tensors travel in ~256 MB buckets, one open bucket per dtype (few, large broadcasts: xGMI is
     point-to-point, so per-call latency and per-link bandwidth, not switch fan-out, set the cost).
@@ -103,7 +110,9 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
     GPU over xGMI, no host staging on the receiving ranks; with matrix_dtype "bf16" / "f16" (16-bit engines;
     `bf16_matrices=True` is the older spelling of "bf16") the weight matrices are rounded to that type ONCE on rank 0 and
     travel as 16-bit words (3.1 GB instead of 6.2 GB for large-v3; every rank, rank 0 included, loads the same bits).
-    gloo backend (CPU tests): float32 host buckets, host arrays out."""
+    gloo backend (CPU tests): float32 host buckets, host arrays out; `host_16bit=True` makes the gloo path use the SAME
+    per-dtype bucket plan and 16-bit travel as the RCCL path (values come out as float32 arrays holding the rounded numbers), so
+    that the multi-dtype send / receive order is exercised by the CPU multi-rank tests."""
     if matrix_dtype is None and bf16_matrices:
         matrix_dtype = "bf16"
     if matrix_dtype not in (None, "bf16", "f16"):
@@ -117,7 +126,7 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
     dev = torch.device(f"cuda:{device}") if on_dev else torch.device("cpu")
     specs = synth.tensor_specs(dims)
     sizes = [int(np.prod(sp[1])) for sp in specs]
-    kinds = [1 if (on_dev and matrix_dtype and _is_matrix(sp[0], sp[1])) else 0 for sp in specs]
+    kinds = [1 if ((on_dev or host_16bit) and matrix_dtype and _is_matrix(sp[0], sp[1])) else 0 for sp in specs]
     esz = (4, 2)
     dts = (torch.float32, torch.float16 if matrix_dtype == "f16" else torch.bfloat16)
     codes = (0, 2 if matrix_dtype == "f16" else 1)     # TTASR_DTYPE_F32 / _BF16 / _F16
@@ -144,7 +153,7 @@ def broadcast_tensors(dims: WhisperDims, src_iter: Optional[Iterable[Tuple[str, 
             for k in plan[b]:
                 yield specs[k][0], DeviceTensor(flat.data_ptr() + where[k][1] * esz[k0], codes[k0], tuple(specs[k][1]))
         else:
-            host = flat.numpy()
+            host = flat.float().numpy() if k0 else flat.numpy()
             for k in plan[b]:
                 yield specs[k][0], host[where[k][1]:where[k][1] + sizes[k]].reshape(specs[k][1])
         del flat                              # the consumer has loaded every view (load_weights is synchronous)

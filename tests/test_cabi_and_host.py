@@ -290,34 +290,50 @@ def test_file_feature_max_never_runs_on_a_reduced_audio_context():
     assert m.engine.ctx == m.dims.n_audio_ctx and m.engine.calls[-1] == ("ctx", m.dims.n_audio_ctx)
 
 
-def test_adapter_retries_without_vad_only_when_a_vad_source_is_configured():
-    """faster_whisper_asr.py:186-196: an empty result with vad_filter=True is retried once with VAD off.  Here the retry is
-    live only when a VAD source exists (without one vad_filter=True already keeps the whole clip)."""
+def test_adapter_returns_none_for_a_vad_emptied_chunk_and_retries_only_on_opt_in():
+    """faster_whisper_asr.py:186-198: the reference's retry re-opens a temp file it deleted at :179, always falls into
+    `except: pass` and returns None - so a chunk the VAD empties yields None.  That is the default here; the
+    retry is an explicit opt-in (`retry_without_vad=True`), live only when a VAD source exists, and its segments are dropped when
+    the decoder itself marks them silent (no_speech_prob) or unlikely (avg_logprob)."""
     import asyncio
     from taiwan_tongues_asr_ce_amd.asr import MI355XWhisperASR
 
     class Seg:
-        def __init__(self, text):
+        def __init__(self, text, no_speech_prob=0.0, avg_logprob=-0.1):
             self.text, self.start, self.end, self.words = text, 0.0, 1.0, None
+            self.no_speech_prob, self.avg_logprob = no_speech_prob, avg_logprob
 
     class Pipe:
-        def __init__(self, prob_fn):
-            self.vad_speech_prob_fn, self.calls = prob_fn, []
+        def __init__(self, prob_fn, retry_segs):
+            self.vad_speech_prob_fn, self.calls, self.retry_segs = prob_fn, [], retry_segs
 
         def transcribe(self, audio, **kw):
             self.calls.append(kw["vad_filter"])
-            return iter([] if kw["vad_filter"] else [Seg("重試成功")]), type("I", (), {"language": "zh", "language_probability": 1.0})()
+            return iter([] if kw["vad_filter"] else self.retry_segs), type("I", (), {"language": "zh", "language_probability": 1.0})()
 
     client = type("C", (), {"scratch_buffer": (np.zeros(1600, "<i2")).tobytes(), "last_start_time": 0})()
-    for prob_fn, want_calls, want_text in ((lambda a: np.zeros(4), [True, False], "重試成功"), (None, [True], None)):
+    fn = lambda a: np.zeros(4)  # noqa: E731
+    cases = (  # (VAD source, opt-in, segments of the retry) -> (transcribe calls, text)
+        (fn, False, [Seg("重試成功")], [True], None),                      # default: the reference's effective behaviour
+        (fn, True, [Seg("重試成功")], [True, False], "重試成功"),          # opt-in retry
+        (None, True, [Seg("重試成功")], [True], None),                     # no VAD source: vad_filter=True kept the whole clip already
+        (fn, True, [Seg("幻覺", no_speech_prob=0.9)], [True, False], None),    # the decoder calls the chunk silence
+        (fn, True, [Seg("幻覺", avg_logprob=-1.7)], [True, False], None),      # a low-confidence guess
+    )
+    for prob_fn, opt_in, retry_segs, want_calls, want_text in cases:
         a = object.__new__(MI355XWhisperASR)
-        a.asr_pipeline = Pipe(prob_fn)
+        a.asr_pipeline = Pipe(prob_fn, retry_segs)
         a.default_transcribe_kwargs = {"word_timestamps": False, "vad_filter": True, "beam_size": 5,
                                        "condition_on_previous_text": True, "initial_prompt": "繁體中文"}
         a.text_filter = None
+        a.retry_without_vad, a.retry_no_speech_threshold, a.retry_logprob_threshold = opt_in, 0.6, -1.0
         out = asyncio.run(a.transcribe(client))
         assert a.asr_pipeline.calls == want_calls
         assert (out["text"] if out else None) == want_text
+    # a speech-probability source in the adapter's default kwargs counts as a VAD source too
+    a.asr_pipeline = Pipe(None, [Seg("x")])
+    a.default_transcribe_kwargs["vad_speech_prob_fn"] = fn
+    assert a._vad_is_active()
 
 
 def test_every_set_option_key_is_documented_in_the_header():

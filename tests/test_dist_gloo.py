@@ -165,3 +165,79 @@ def test_forced_single_rank_group_runs_the_collective_paths():
     assert q.get(timeout=180) is True
     p.join(60)
     assert p.exitcode == 0
+
+
+def _world4_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from taiwan_tongues_asr_ce_amd import synth
+    from taiwan_tongues_asr_ce_amd.config import PRESETS
+    from taiwan_tongues_asr_ce_amd.dist import _is_matrix, broadcast_tensors, bucket_plan, gather_tokens, init_process_group, shard_range
+    r, w, _ = init_process_group("gloo")
+    dims = PRESETS["micro"]
+    specs = synth.tensor_specs(dims)
+    bucket_bytes = 64 << 10                      # small buckets: many of them, both dtype classes interleaved
+    src = synth.iter_weights(dims) if r == 0 else None
+    order, ok = [], True
+    full = synth.state_dict(dims)
+    for name, arr in broadcast_tensors(dims, src, bucket_bytes=bucket_bytes, matrix_dtype="bf16", host_16bit=True):
+        order.append(name)
+        ref = full[name]
+        if _is_matrix(name, ref.shape):         # travelled as bf16: rounded once on rank 0
+            ref = torch.from_numpy(ref).to(torch.bfloat16).float().numpy()
+        ok = ok and np.array_equal(np.asarray(arr), ref)
+    # the receive order every rank must follow = the bucket plan's order (buckets by their last tensor, tensors ascending inside)
+    sizes = [int(np.prod(s[1])) for s in specs]
+    kinds = [1 if _is_matrix(s[0], s[1]) else 0 for s in specs]
+    plan = bucket_plan(sizes, kinds, bucket_bytes, (4, 2))
+    want = [specs[k][0] for b in plan for k in b]
+    # uneven shards: 10 clips over 4 ranks = 3 + 3 + 2 + 2, padded to the largest shard for the all-gather
+    lo, hi = shard_range(10, r, w)
+    n_max = max(shard_range(10, rr, w)[1] - shard_range(10, rr, w)[0] for rr in range(w))
+    toks = [[1000 * c + j for j in range(1 + c % 3)] for c in range(lo, hi)] + [[]] * (n_max - (hi - lo))
+    allt = gather_tokens(toks, 4)
+    q.put((r, bool(ok), order == want, len(plan), allt.tolist(), (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_uneven_shards_and_multi_dtype_receive_order():
+    """four ranks, uneven shards (10 clips = 3 + 3 + 2 + 2), and the per-dtype bucket plan with 16-bit
+    travel on every rank: rank != 0 walks `range(len(plan))`, rank 0 emits buckets as they fill - both must produce the plan's
+    order and the same (rounded-once) values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(4))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [x[5] for x in res] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert all(x[1] for x in res), "values differ from the rounded-once reference"
+    assert all(x[2] for x in res), "a rank yielded tensors in an order other than the bucket plan's"
+    assert res[0][3] >= 6                      # the plan really had several buckets of both classes
+    assert all(x[4] == res[0][4] for x in res)
+    allt = np.array(res[0][4])
+    assert allt.shape == (12, 4)               # 4 ranks x the largest shard (3 rows), padded rows all -1
+    rows = {tuple(t) for t in allt.tolist()}
+    for c in range(10):
+        want = [1000 * c + j for j in range(1 + c % 3)]
+        assert tuple(want + [-1] * (4 - len(want))) in rows
+    assert allt[8].tolist() == [-1] * 4 and allt[11].tolist() == [-1] * 4   # the padding rows of the 2-clip shards
+
+
+def test_missing_master_port_fails_fast_for_a_real_group(monkeypatch):
+    """with WORLD_SIZE > 1 and no MASTER_PORT every rank would bind a different free port and the rendezvous
+    would hang; only the forced single-rank group may pick its own."""
+    import pytest
+    from taiwan_tongues_asr_ce_amd import dist as D
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        D.init_process_group("gloo")
