@@ -164,6 +164,31 @@ def _cpu_model():
     return "unknown"
 
 
+def xattn_traffic_from_profile(xp: dict, sig: str, B: int):
+    """(traffic bytes per launch | None, note): the committed PMC profile of the dominant kernel is used ONLY when it was taken on
+    the kernel signature (name, template arguments, grid) this run launched - otherwise null plus the reason, never a stale number."""
+    sigs = xp.get("signatures") or []
+    if sig and sig in sigs:
+        return (round(xp["traffic_bytes_per_32row_launch"] * B / 32.0),
+                f"profiles/xattn_pmc.json, taken on `{sig}` = the kernel this run launched (static: separate rocprofv3 --pmc passes, "
+                f"not re-measured by this run)")
+    return None, (f"stale profile: profiles/xattn_pmc.json was taken on {sigs or [xp.get('kernel')]}, this run launched `{sig}` - "
+                  f"re-run the --pmc passes (tools/gpu_session.sh)")
+
+
+def pmc_busy_from_profile(kernels: dict, sigs, flops):
+    """(flop-weighted MFMA-busy fraction | None, note) of the kernels with signatures `sigs` from a committed *_pmc.json; None when
+    any of them has no entry taken on exactly that signature."""
+    fr = []
+    for sig in sigs:
+        hit = [v["mfma_busy_frac"] for v in kernels.values() if sig and sig in v.get("signatures", []) and "mfma_busy_frac" in v]
+        if not hit:
+            return None, (f"stale profile: no entry taken on `{sig}` (the encoder GEMM kernels this run launched: {list(sigs)}) - "
+                          f"re-run the --pmc passes (tools/gpu_session.sh)")
+        fr.append(hit[0])
+    return round(sum(flops) / sum(f / b for f, b in zip(flops, fr)), 4), None
+
+
 def _self_launch(n: int) -> int:
     """`python bench.py --gpus N` from a bare shell (no torchrun environment): this parent process touches no GPU - it
     only spawns the N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set exactly as
@@ -269,6 +294,11 @@ def main():
     ap.add_argument("--cpu-full", action="store_true",
                     help="run ONE full large-v3 B = 1 pass of the CPU oracle (minutes) and cache it as profiles/cpu_baseline_full.json")
     ap.add_argument("--write-crc", action="store_true", help="record the token checksum of this run as the expected one")
+    ap.add_argument("--xkv-fp8", action="store_true",
+                    help="opt-in serving mode (NOT the headline): OCP e4m3 copy of the cross-KV cache read by the decode step's "
+                         "cross-attention (ttasr_set_option xkv_fp8); the line's dtype says so and output_check reports the token "
+                         "agreement with the bf16 and the f32 engines")
+    ap.add_argument("--dump-tokens", default=None, help="save rank 0's int32 [B][new_tokens] token ids of the last timed step as .npy")
     ap.add_argument("--clips", default="noise", choices=["noise", "tonal"],
                     help="synthetic clip set of the timed steps (SURVEY.md 8d: 0.1 N(0,1) noise; the tonal set - five sines - is "
                          "also measured as a side number by the default run)")
@@ -297,6 +327,11 @@ def main():
     compute = {"bf16": COMPUTE_BF16, "f16": COMPUTE_F16, "f32": COMPUTE_F32}[args.compute]
     engines = [Engine(dims, compute, B, device=local) for _ in range(C_)]
     eng = engines[0]
+    if args.xkv_fp8:
+        if args.compute == "f32":
+            raise SystemExit("--xkv-fp8 needs a 16-bit engine")
+        for e_ in engines:
+            e_.set_option("xkv_fp8", 1)
     t_load = time.perf_counter()
     for e_ in engines:
         if grp and os.environ.get("TTASR_BENCH_LOCAL_WEIGHTS") is None:
@@ -413,7 +448,9 @@ def main():
         n_cmp, n_agree, worst = _host_greedy_prefix(eng, B, prompt, mine, n_chk, [opts.suppress[i] for i in range(opts.n_suppress)],
                                                     [opts.begin_suppress[i] for i in range(opts.n_begin_suppress)], st.eot)
         crc = zlib.crc32(np.ascontiguousarray(mine).tobytes()) & 0xFFFFFFFF
-        key = f"{args.model}/b{B}/n{args.new_tokens}/{args.compute}"
+        if args.dump_tokens:
+            np.save(args.dump_tokens, np.ascontiguousarray(mine))
+        key = f"{args.model}/b{B}/n{args.new_tokens}/{args.compute}" + ("+xkv_fp8" if args.xkv_fp8 else "")
         crc_path = os.path.join(ROOT, "profiles", "bench_tokens_crc.json")
         try:
             with open(crc_path) as f:
@@ -424,10 +461,31 @@ def main():
             known[key] = crc
             with open(crc_path, "w") as f:
                 json.dump(known, f, indent=1, sort_keys=True)
+        # (iv) agreement with the f32 PARITY engine's tokens on this very workload (north_star: token-for-token at greedy decode):
+        # profiles/bench_tokens_f32.npy is the [32][128] output of `bench.py --compute f32 --dump-tokens` (the f32 engine is the
+        # one that meets the 1e-3 / token-exact gate against the oracle at this geometry, tests/test_gpu_full_size.py).  Greedy
+        # decoding is not teacher-forced, so once a row diverges the rest of it is a different sentence: the numbers reported are
+        # the rows that never diverge, each row's first divergent position, and the equal-prefix fraction of all tokens.
+        def agreement(ref_file):
+            try:
+                ref = np.load(os.path.join(ROOT, "profiles", ref_file))
+            except Exception:
+                return None
+            if not (args.model == "large-v3" and args.clips == "noise" and ref.shape[0] >= B and ref.shape[1] >= args.new_tokens):
+                return None
+            neq = mine != ref[:B, :args.new_tokens]
+            first = np.where(neq.any(axis=1), neq.argmax(axis=1), args.new_tokens)
+            return {"rows_identical": int((first == args.new_tokens).sum()), "rows": int(B),
+                    "equal_prefix_fraction": round(float(first.sum()) / (B * args.new_tokens), 4),
+                    "first_divergence_per_row": [int(x) for x in first],
+                    "source": f"profiles/{ref_file} (same clips / weights / prompt)"}
+        vs_f32 = agreement("bench_tokens_f32.npy")
+        vs_bf16 = agreement("bench_tokens_bf16.npy") if (args.xkv_fp8 or args.compute != "bf16") else None
         tol = {"bf16": 0.05, "f16": 0.0125, "f32": 1e-3}[args.compute]
         check = {"replay_bit_identical": bool(replay_equal), "prefix_choices_recomputed_via_step_api": n_cmp,
                  "prefix_choices_equal": n_agree, "largest_margin_at_a_disagreement": round(worst, 5), "margin_tolerance": tol,
-                 "tokens_crc32": crc, "expected_crc32": known.get(key), "crc_match": (known.get(key) == crc) if key in known else None}
+                 "tokens_crc32": crc, "expected_crc32": known.get(key), "crc_match": (known.get(key) == crc) if key in known else None,
+                 "vs_f32_parity_tokens": vs_f32, "vs_bf16_engine_tokens": vs_bf16}
         if worst > tol or n_agree < 0.9 * n_cmp or not replay_equal:
             raise SystemExit(f"output check failed: {check}")
         # the recomputation moved the decode state: rebuild the step's state for the kernel measurements below
@@ -441,15 +499,19 @@ def main():
         achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately
         # and committed as profiles/xattn_pmc.json; gfx950 x2 FETCH_SIZE correction applied there)
-        traffic = None
+        # ... and only when that profile describes the kernel THIS run launches: the library reports the signature of what
+        # ttasr_bench_kernel launched (kernel name, template arguments, grid), the profile lists the signatures it was taken on;
+        # a kernel change without a PMC refresh yields traffic = null plus the reason, never a stale number
+        traffic, traffic_note = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "xattn_pmc.json")) as f:
-                traffic = round(json.load(f)["traffic_bytes_per_32row_launch"] * B / 32.0)
-        except Exception:
-            pass
-        roof = {"kernel": "cross_attn_decode_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
+                traffic, traffic_note = xattn_traffic_from_profile(json.load(f), k.get("signature"), B)
+        except Exception as ex:
+            traffic_note = f"profiles/xattn_pmc.json unreadable: {ex}"
+        roof = {"kernel": (k.get("signature") or "cross_attn_decode_kernel").split("<")[0], "kernel_signature": k.get("signature"),
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                "traffic_source": "profiles/xattn_pmc.json (static: separate rocprofv3 --pmc passes, not re-measured by this run)",
+                "traffic_source": traffic_note,
                 "avg_launch_us": round(k["ms"] * 1e3, 2), "bytes_per_launch": k["bytes"]}
         # encoder GEMMs (the four shapes of one layer), flop-weighted: total flops / total time.
         # (i) IN SITU: one extra untimed pass of the real encoder schedule with a hipEvent after
@@ -480,21 +542,13 @@ def main():
         gs = [eng.bench_kernel(n, B, iters=30) for n in names]
         enc_tf = sum(x["flops"] for x in gs) / (sum(x["ms"] for x in gs) * 1e-3) / 1e12
         # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent; static, like traffic)
-        pmc_busy, pmc_file = None, None
+        pmc_busy, pmc_file, pmc_note = None, None, None
         try:
-            pmc_file = next(f_ for f_ in ("r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            pmc_file = next(f_ for f_ in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
-                kk_ = json.load(f)["kernels"]
-
-            def busy(prefix, grid):
-                return next(v["mfma_busy_frac"] for k_, v in kk_.items() if k_.startswith(prefix) and k_.endswith(f"grid {grid}"))
-            nt_m = (B * dims.n_audio_ctx + 255) // 256
-            g_qkv, g_d, g_f = nt_m * (3 * dims.d_model // 256) * 512, nt_m * (dims.d_model // 256) * 512, nt_m * (dims.ffn_dim // 256) * 512
-            fr = [busy("enc GEMM bias -> bf16", g_qkv), busy("enc GEMM bias -> bf16", g_d), busy("enc GEMM bias + GELU", g_f),
-                  busy("enc GEMM bias -> bf16", g_d)]
-            pmc_busy = round(sum(x["flops"] for x in gs) / sum(x["flops"] / f_ for x, f_ in zip(gs, fr)), 4)
-        except Exception:
-            pass
+                pmc_busy, pmc_note = pmc_busy_from_profile(json.load(f)["kernels"], [x.get("signature") for x in gs], [x["flops"] for x in gs])
+        except Exception as ex:
+            pmc_note = f"PMC profile unreadable: {ex}"
         ph = {kk: round(float(np.mean([p[kk] for p in phases])), 2) for kk in phases[0]}
         # phase-level fractions.  Decode: SURVEY.md 8(d)'s algorithmic bytes per step at the mean
         # position - decoder weights (every decoder-layer matrix + the tied embedding, read once per step for the whole batch)
@@ -515,7 +569,8 @@ def main():
             "value": round(world * C_ * B * 30.0 * args.steps / dt, 2), "unit": "audio-s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.compute, "data": "synthetic",
+            "dtype": args.compute + (" + fp8 (e4m3) cross-KV cache: opt-in serving mode, not the headline configuration" if args.xkv_fp8 else ""),
+            "data": "synthetic",
             "config": {"workload": f"whisper-{args.model} geometry (random-init seeded weights), " + (f"{C_} concurrent contexts x " if C_ > 1 else "") + f"{B} x 30 s 16 kHz synthetic "
                                    f"clips per GPU resident in HBM, log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
@@ -537,7 +592,8 @@ def main():
                      "encoder_phase_frac": round(enc_phase_flops / (ph["encoder"] * 1e-3) / 2.5e15, 4),
                      "cross_kv_phase_frac": round(cls_flops["cross_kv"] / (ph["cross_kv"] * 1e-3) / 2.5e15, 4),
                      "isolated_relaunch_tflops": round(enc_tf, 1), "isolated_relaunch_frac": round(enc_tf / 2500.0, 4),
-                     "pmc_mfma_busy_frac": pmc_busy, "pmc_source": f"profiles/{pmc_file} (static)" if pmc_busy is not None else None},
+                     "pmc_mfma_busy_frac": pmc_busy,
+                     "pmc_source": f"profiles/{pmc_file} (static; entries matched by kernel signature)" if pmc_busy is not None else pmc_note},
         }
         if world == 1 and C_ == 1 and args.clips == "noise":
             # SURVEY.md 8(d)'s tonal variant (five sines: exercises the per-clip max - 8 clamp of the log-mel): the same step on

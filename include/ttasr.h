@@ -205,11 +205,15 @@ int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32_t* out_ro
 /* The release library reads NO environment variable; every deviation from the measured configuration is an explicit call.
  * Keys (value 0 / 1 unless stated; defaults in brackets): "flash" [1] MFMA flash attention in the encoder (0: the
  * one-query-per-wave f32 kernel); "prefill" [1] batched prompt prefill (0: prompts token by token); "vocab_persistent" [1] persistent vocabulary GEMM; "xsplit" [1] frame-split
- * cross-attention for small batches; "graph" [1] hipGraph replay of the decode step; "generic_kernels" [0] the 64x64 generic
+ * cross-attention for small batches; "graph" [1] hipGraph replay of the decode step; "multi_step_graph" [1] runs of 8 / 4 greedy
+ * steps between two host polls replay as one graph; "generic_kernels" [0] the 64x64 generic
  * GEMM / per-row kernels everywhere; "prefill_tiled" [0]; "prefill_ns_min" [2] (tokens); "enc_residual_epilogue" [0];
- * "enc_gemm" [0] = 1 | 2 | 3 forces one encoder GEMM kernel; "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =
- * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "weights_nontemporal" [1] (these two are process-wide);
- * "enc_kernel_timing" [0] per-launch events in ttasr_encode (see ttasr_encoder_kernel_ms).
+ * "enc_gemm" [0] = 1 | 2 | 3 | 4 forces one encoder GEMM kernel; "enc_gemm_persistent" [0] persistent 256x256 GEMM workgroups; "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =
+ * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "xattn_pipeline" [1] (software-pipelined cross-attention), "weights_nontemporal" [1] (all per context
+ * since round 4);
+ * "enc_kernel_timing" [0] per-launch events in ttasr_encode (see ttasr_encoder_kernel_ms); "xkv_fp8" [0] (16-bit engines; opt-in serving
+ * mode, NOT the measured configuration) keeps an OCP e4m3 copy of the cross-KV cache with one scale per (layer, K | V, clip, head),
+ * built by the next ttasr_encode and read by the decode step's cross-attention (half the bytes of the dominant kernel).
  * Drops the captured decode graphs.  Unknown key or value out of range: TTASR_E_INVALID. */
 int ttasr_set_option(ttasr_ctx* ctx, const char* key, int32_t value);
 
@@ -229,6 +233,11 @@ int ttasr_encoder_kernel_ms(ttasr_ctx* ctx, float out_ms[8]);
  * "enc_gemm_qkv", "enc_gemm_out", "enc_gemm_fc1", "enc_gemm_fc2", "enc_attn", "dec_gemm_fc1", "logits_gemm". */
 int ttasr_bench_kernel(ttasr_ctx* ctx, const char* name, int32_t B, int32_t iters, float* out_avg_ms,
                        double* out_bytes_per_launch, double* out_flops_per_launch);
+/* Signature of the kernel the LAST ttasr_bench_kernel call on this context launched, in the spelling rocprofv3 prints it
+ * ("kernel_name<template arguments> grid <threads>"; "" when that kernel's launcher records none: names "xattn" and "enc_gemm_*"
+ * do).  bench.py compares it with the signature stored in the committed counter profiles (profiles/xattn_pmc.json, *_pmc.json)
+ * and reports their numbers only when they describe the kernel this build launches. */
+int ttasr_bench_kernel_signature(ttasr_ctx* ctx, char* buf, int32_t len);
 /* Device-wide synchronisation of the context's stream. */
 int ttasr_sync(ttasr_ctx* ctx);
 

@@ -35,6 +35,11 @@ template <> struct N16<bf16_t> {
   static __device__ __forceinline__ uint16_t down(float f) { return f2bf(f); }
   static __device__ __forceinline__ f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  // c + a.lo * b.lo + a.hi * b.hi on one dword of two stored values each (v_dot2c_f32_bf16: f32 accumulate)
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a), __builtin_bit_cast(bf16x2_hw, b), c, false);
+  }
 };
 template <> struct N16<f16_t> {
   static __device__ __forceinline__ float up(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
@@ -43,9 +48,10 @@ template <> struct N16<f16_t> {
     lo = (float)v[0]; hi = (float)v[1];
   }
   // Saturating: |v| > 65504 would become inf and turn into NaN in the next LayerNorm / softmax; HF clamps its
-  // fp16 hidden states for the same reason (modeling_whisper.py:403-407).  A NaN stays a NaN (fmaxf / fminf alone would turn
-  // it into a finite number and hide an upstream fault).
-  static __device__ __forceinline__ float sat(float v) { return v != v ? v : __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
+  // fp16 hidden states for the same reason (modeling_whisper.py:403-407).  ONE v_med3_f32 per value (the compare / max / min /
+  // select form that also kept a NaN a NaN cost 3.6 ms per encoder pass at large-v3: 128 values per lane and GEMM tile); med3
+  // maps a NaN input to -65504, so a NaN can no longer be used to spot an upstream fault in the fp16 mode.
+  static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
   static __device__ __forceinline__ uint32_t pk(float lo, float hi) {   // round-to-nearest-even, one v_cvt_pk_f16_f32
     typedef float f32x2_hw __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){sat(lo), sat(hi)}, h16x2_hw));
@@ -56,6 +62,9 @@ template <> struct N16<f16_t> {
   }
   static __device__ __forceinline__ f32x4 mfma16(s16x8 a, s16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {   // v_dot2c_f32_f16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_hw, a), __builtin_bit_cast(h16x2_hw, b), c, false);
   }
 };
 // 8 stored values (one 16-byte chunk) -> f32
@@ -175,6 +184,8 @@ template <typename T16> void launch_gemm_bf16_v2(const GemmArgs& g, hipStream_t 
 bool gemm_bf16_v2_ok(const GemmArgs& g);
 template <typename T16> void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s);
 bool gemm_bf16_v3_ok(const GemmArgs& g);
+template <typename T16> void launch_gemm_bf16_v4(const GemmArgs& g, hipStream_t s);   // persistent form of v3 (T-output epilogues)
+bool gemm_bf16_v4_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
@@ -188,7 +199,7 @@ void launch_layernorm_add(float* x, const T* delta, const float* gamma, const fl
 struct LnPre {
   const float* bias = nullptr;   // [d]
   const float* slab = nullptr;   // [n_slab][slab_stride] f32 partial tiles of the preceding K-split residual GEMM
-  int n_slab = 0;                // <= 16
+  int n_slab = 0;                // <= 20
   int64_t slab_stride = 0;
   float* x_out = nullptr;        // [rows][d] updated residual rows (may alias x)
   const int32_t* tok = nullptr;  // [rows]
@@ -208,6 +219,14 @@ struct SlabIn {
   int n = 0;
   int64_t stride = 0;
   int ld = 0;
+};
+
+// cross-attention query computed inside the attention kernel (round-4 experiment): x = LayerNorm output rows T [B][d],
+// W = the q projection T [d][d] row-major (pre-scaled by 1/8), bias f32 [d]; W == nullptr: not used
+struct QProj {
+  const void* x = nullptr;
+  const void* W = nullptr;
+  const float* bias = nullptr;
 };
 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
@@ -292,7 +311,21 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
                               float* split_ws = nullptr /*[B*H*8][66]: enables the split-frame variant for small B*H*/,
                               SlabIn sq = SlabIn{} /*q from K-split partial tiles*/,
                               int ws_rows = 0 /*rows the workspace was sized for (0: B); rows that share a clip (kv_div 2..8)
-                                                are served by one K/V stream per clip when they fit*/);
+                                                are served by one K/V stream per clip when they fit*/,
+                              QProj qp = QProj{} /*W != nullptr: the query is projected inside the kernel (B * H >= 256, kv_div == 1)*/);
+// Signature of the kernel a launcher picked, in the spelling rocprofv3 prints ("name<template arguments> grid <threads>"):
+// recorded by the launchers of the measured kernels while g_kernel_sig_on is set (ttasr_bench_kernel), so that bench.py can tell
+// whether a committed counter profile still describes what the run launches.
+// opt-in fp8 (e4m3) copy of the cross-KV cache and the decode-step cross-attention that reads it (kernels_fp8.hip)
+template <typename T> void launch_xkv_quant(const T* src, uint8_t* dst, float* scale, int64_t n_blocks, int rows, hipStream_t s);
+template <typename T>
+bool launch_cross_attn_fp8(const T* q, const uint8_t* K8, const uint8_t* V8, const float* kscale, const float* vscale, T* out, int B, int H,
+                           int Tk, hipStream_t s, struct SlabIn sq);
+extern thread_local bool g_kernel_sig_on;
+extern thread_local char g_kernel_sig[192];
+template <typename T> inline const char* sig_type() { return sizeof(T) == 4 ? "float" : "unsigned short"; }
+template <> inline const char* sig_type<struct f16_t>() { return "f16_t"; }
+
 // Kernel-variant switches of the launchers (A/B experiments).  Thread-local: every C-ABI call copies its CONTEXT's setting in
 // before it launches anything (engine.hip guarded()), so an option set on one context never changes what another context's
 // thread launches or what its captured graphs hold.

@@ -79,6 +79,9 @@ struct ttasr_ctx {
   float* mel = nullptr; void* mel_t = nullptr; void* c1 = nullptr;
   float* x = nullptr; void *h = nullptr, *qkv = nullptr, *att = nullptr, *mid = nullptr, *enc_out = nullptr;
   void* xkv = nullptr; int64_t xkv_layer_elems = 0, xkv_which_elems = 0;
+  // option xkv_fp8 (opt-in serving mode, kernels_fp8.hip): an e4m3 copy of the cross-KV cache (same element strides, one byte per
+  // value) + one f32 scale per (layer, K | V, clip, head); read by the decode step's cross-attention only
+  bool xkv_fp8 = false, xkv8_valid = false; uint8_t* xkv8 = nullptr; float* xkv8_scale = nullptr;
   void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
   float* xsplit_ws = nullptr;  // split-frame cross-attention (small batches)
   float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
@@ -94,7 +97,8 @@ struct ttasr_ctx {
 #endif
   float* slab = nullptr;      // [16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
   int ks_want[4] = {0, 0, 0, 0};  // option ksplit_out / _q / _qkv / _fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
-  int gemm_force = 0;         // option enc_gemm = 1|2|3 (A/B testing of the encoder GEMM kernels)
+  int gemm_force = 0;         // option enc_gemm = 1|2|3|4 (A/B testing of the encoder GEMM kernels)
+  bool gemm_persistent = false;  // option enc_gemm_persistent: the persistent 256x256 GEMM where a workgroup has >= 2 tiles
   bool vocab_persistent = true;  // option vocab_persistent = 0: the one-workgroup-per-32-outputs kernel for the vocabulary projection (A/B)
   bool no_flash = false;      // option flash = 0
   int prefill_ns_min = 2;     // option prefill_ns_min: shortest prompt (positions before the last) whose <|startoftranscript|> position is taken
@@ -108,11 +112,13 @@ struct ttasr_ctx {
 
   int B_mel = 0, B_enc = 0, B_dec = 0;
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
-  int xattn_nt = 1, weights_nt = 1;  // options xattn_nontemporal / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
+  int xattn_nt = 1, xattn_pipe = 1, weights_nt = 1;  // options xattn_nontemporal / xattn_pipeline / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
+  bool multi_step = true;   // option multi_step_graph = 0: one graph replay per decode step (A/B testing)
   bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)
   bool prefill_tiled = false;  // option prefill_tiled: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
   hipEvent_t ev[8]{};
+  std::string bench_sig;     // signature of the kernel the last ttasr_bench_kernel call launched (ttasr_bench_kernel_signature)
   float phase_ms[4]{0, 0, 0, 0};
   // option enc_kernel_timing: one hipEvent after every launch of run_encoder / run_cross_kv, so the NEXT ttasr_encode also
   // reports where the phase went, in situ (class sums: ttasr_encoder_kernel_ms).  Off in the timed benchmark steps.
@@ -401,11 +407,13 @@ template <typename T>
 void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
-      const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage
+      const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage, 4 = 3 as persistent workgroups
       // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
       const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
-      if ((v ? v == 3 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3<T>(g, c->cur); return; }
+      // persistent form (round 4): pays once a workgroup has several tiles to walk (>= 2 per CU)
+      if ((v ? v == 4 : (c->gemm_persistent && tiles_v3 >= 512)) && gemm_bf16_v4_ok(g)) { launch_gemm_bf16_v4<T>(g, c->cur); return; }
+      if ((v ? v == 3 || v == 4 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3<T>(g, c->cur); return; }
       if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2<T>(g, c->cur); return; }
       if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast<T>(g, c->cur); return; }
     }
@@ -454,8 +462,18 @@ int run_cross_kv(ttasr_ctx* c, int B) {
     g.epi.out_t = (char*)c->xkv + (size_t)l * c->xkv_layer_elems * c->esz;
     g.epi.headsplit = 1; g.epi.hs_T = T_; g.epi.hs_H = c->H; g.epi.hs_d = d; g.epi.hs_which = c->xkv_which_elems;
     gemm<T>(c, g);
+    if constexpr (sizeof(T) == 2) {
+      if (c->xkv_fp8 && c->xkv8) {   // quantise this layer's K and V blocks of the B clips (one workgroup per (clip, head) block)
+        for (int which = 0; which < 2; ++which) {
+          const int64_t off = (int64_t)l * c->xkv_layer_elems + which * c->xkv_which_elems;
+          launch_xkv_quant<T>((const T*)c->xkv + off, c->xkv8 + off, c->xkv8_scale + ((size_t)l * 2 + which) * c->maxB * c->H,
+                              (int64_t)B * c->H, T_, c->cur);
+        }
+      }
+    }
     enc_mark(c, EC_XKV);
   }
+  c->xkv8_valid = c->xkv_fp8 && c->xkv8 != nullptr && sizeof(T) == 2;
   return 0;
 }
 
@@ -615,7 +633,16 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
       if (!sq.n) { g.epi.bias = L.bqx; g.epi.out_t = dq; dec_gemm<T>(c, g, L.wqx_sh); } }
     // cross-KV of clip (row / kv_div); a half-batch offset is only used with kv_div == 1
     const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
-    if (!(c->skip_mask & 8))
+    bool fp8_done = false;
+    if constexpr (sizeof(T) == 2) {   // opt-in: the e4m3 copy of the cache, unshared rows that fill the chip (the single-pass kernel's case)
+      if (c->xkv_fp8 && c->xkv8_valid && c->kv_div == 1 && n * c->H >= 256 && skinny && !(c->skip_mask & 8)) {
+        const int64_t off = (int64_t)l * c->xkv_layer_elems + (int64_t)row0 * c->H * c->T * 64;
+        const float* ksc = c->xkv8_scale + ((size_t)l * 2) * c->maxB * c->H + (size_t)row0 * c->H;
+        fp8_done = launch_cross_attn_fp8<T>((const T*)dq, c->xkv8 + off, c->xkv8 + off + c->xkv_which_elems, ksc, ksc + (size_t)c->maxB * c->H,
+                                            (T*)datt, n, c->H, c->T, s, sq);
+      }
+    }
+    if (!fp8_done && !(c->skip_mask & 8))
       launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
                                   c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq, c->maxB - row0);
     residual_gemm(datt, L.wox, L.wox_sh, L.box, d, 0);
@@ -778,12 +805,15 @@ void run_decode_step(ttasr_ctx* c, int B, int mode) {
   if (mode == 1 || (c->skip_mask & 16)) launch_advance(c->st.step, c->stream);
 }
 
-int step_graph(ttasr_ctx* c, int B, int mode) {
+// `nsteps` consecutive steps of the same mode as ONE graph (round 4): the search state is device-resident, so a run of greedy
+// steps between two host polls needs no host involvement at all; one replay instead of nsteps saves the graph-launch gap
+// (~8 us on the device, 10-16 us of host time per replay) per step.
+int step_graph(ttasr_ctx* c, int B, int mode, int nsteps = 1) {
   if (!c->use_graph) {
-    TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
+    for (int i = 0; i < nsteps; ++i) TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
     return 0;
   }
-  const int variant = c->kv_div * 2 + c->identity_pages;
+  const int variant = (c->kv_div * 2 + c->identity_pages) * 64 + nsteps;
   for (size_t i = 0; i < c->graphs.size(); ++i) {
     if (c->graphs[i].B == B && c->graphs[i].mode == mode && c->graphs[i].variant == variant) {
       // most recently used at the back: the cache is bounded (the streaming micro-batcher varies B from 1 to max_batch rows)
@@ -794,7 +824,7 @@ int step_graph(ttasr_ctx* c, int B, int mode) {
   }
   hipGraph_t graph = nullptr;
   HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
+  for (int i = 0; i < nsteps; ++i) TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
   HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
   hipGraphExec_t exec = nullptr;
   const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -882,18 +912,31 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   else if (key == "vocab_persistent") c->vocab_persistent = on;
   else if (key == "xsplit") c->no_xsplit = !on;
   else if (key == "graph") c->use_graph = on;
+  else if (key == "multi_step_graph") c->multi_step = on;
   else if (key == "generic_kernels") c->force_basic = on;
   else if (key == "prefill_tiled") c->prefill_tiled = on;
   else if (key == "prefill_ns_min") { if (v < 0) return 1; c->prefill_ns_min = v; }
   else if (key == "enc_residual_epilogue") c->enc_res_epilogue = on;
-  else if (key == "enc_gemm") { if (v < 0 || v > 3) return 1; c->gemm_force = v; }
+  else if (key == "enc_gemm") { if (v < 0 || v > 4) return 1; c->gemm_force = v; }
+  else if (key == "enc_gemm_persistent") c->gemm_persistent = on;
   else if (key == "ksplit_out") { if (v < 0 || v > 16) return 1; c->ks_want[0] = v; }
   else if (key == "ksplit_q") { if (v < 0 || v > 16) return 1; c->ks_want[1] = v; }
   else if (key == "ksplit_qkv") { if (v < 0 || v > 16) return 1; c->ks_want[2] = v; }
   else if (key == "ksplit_fc2") { if (v < 0 || v > 16) return 1; c->ks_want[3] = v; }
-  else if (key == "xattn_nontemporal") g_xattn_variant = c->xattn_nt = on ? 1 : 0;   // per context (kernel template choice)
-  else if (key == "weights_nontemporal") g_skinny_nt = c->weights_nt = on ? 1 : 0;
+  else if (key == "xattn_nontemporal") c->xattn_nt = on ? 1 : 0;   // per context (kernel template choice)
+  else if (key == "xattn_pipeline") c->xattn_pipe = on ? 1 : 0;
+  else if (key == "xkv_fp8") {
+    if (on && !c->lowp) return 1;   // 16-bit engines only
+    if (on && !c->xkv8) {
+      const size_t n = (size_t)c->cfg.dec_layers * c->xkv_layer_elems;
+      if (dalloc(c, &c->xkv8, n, false) != 0 || dalloc(c, &c->xkv8_scale, (size_t)c->cfg.dec_layers * 2 * c->maxB * c->H * sizeof(float)) != 0)
+        return 1;
+    }
+    c->xkv_fp8 = on; c->xkv8_valid = false;   // the e4m3 copy is (re)built by the next encode
+  }
+  else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
   else return 1;
+  g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt;
   drop_graphs(c);
   return 0;
 }
@@ -928,7 +971,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
-  if (c) { g_xattn_variant = c->xattn_nt; g_skinny_nt = c->weights_nt; }   // this context's kernel variants for everything f launches
+  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; }   // this context's kernel variants for everything f launches
   try {
     return f();
   } catch (const std::bad_alloc&) {
@@ -1372,7 +1415,15 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   for (int step = pre; step < last_step; ++step) {
     const bool all_forced = step + 1 < min_plen;
     const bool need_logits = !all_forced || (o->no_speech >= 0 && step == o->sot_index);
-    TRY(step_graph(c, R, need_logits ? 0 : 2));
+    // runs of sampled steps up to (and including) the next host poll replay as ONE multi-step graph of 8 or 4 steps
+    int run = 1;
+    if (c->multi_step && need_logits && step + 1 >= min_plen) {
+      int until_poll = last_step - step;                       // steps left
+      if (!o->suppress_eot) until_poll = std::min(until_poll, interval - (step + 1 - min_plen) % interval);
+      run = until_poll >= 8 ? 8 : (until_poll >= 4 ? 4 : 1);
+    }
+    TRY(step_graph(c, R, need_logits ? 0 : 2, run));
+    step += run - 1;
     if (!o->suppress_eot && step + 1 >= min_plen && ((step + 1 - min_plen) % interval == interval - 1)) {
       HIPCHK(c, hipMemcpyAsync(c->pinned_i32, c->st.n_done, 4, hipMemcpyDeviceToHost, s));
       HIPCHK(c, hipStreamSynchronize(s));
@@ -1844,8 +1895,14 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
       constexpr bool same_layer = false;
 #endif
       const char* Kx = (const char*)c->xkv + (size_t)(same_layer ? 0 : layer_rr++ % c->cfg.dec_layers) * c->xkv_layer_elems * c->esz;
+      // the instantiation the decode step launches: 16-bit engines read the query from the q GEMM's K-split partial tiles
+      SlabIn sqb;
+      if (c->lowp && !c->force_basic && c->slab) {
+        const int ks = gemm_skinny_ksplit(B, c->d, c->d, c->ks_want[1] ? c->ks_want[1] : 4);
+        if (ks > 1) { sqb.slab = c->slab; sqb.bias = c->dec[0].bqx; sqb.n = ks; sqb.stride = (int64_t)c->maxB * c->d; sqb.ld = c->d; }
+      }
       TT_DISPATCH(c, launch_cross_attn_decode<T>((const T*)c->dq, (const T*)Kx, (const T*)Kx + c->xkv_which_elems, (T*)c->datt, B, c->H,
-                                                 c->T, 1, s));
+                                                 c->T, 1, s, nullptr, sqb));
       bytes = (double)B * (2.0 * T_ * d + 2.0 * d) * e; flops = (double)B * 4.0 * T_ * d;
     } else if (k == "xattn_beam5" || k == "xattn_beam5_rows") {
       // B rows = B / 5 clips x 5 hypotheses sharing their clip's cross-KV: one stream per clip ("xattn_beam5") or the
@@ -1905,7 +1962,11 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
     }
     return 0;
   };
-  TRY(once());
+  g_kernel_sig[0] = 0; g_kernel_sig_on = true;
+  const int rc_first = once();
+  g_kernel_sig_on = false;
+  c->bench_sig = g_kernel_sig;   // "" when the launcher of this kernel records none
+  TRY(rc_first);
   HIPCHK(c, hipStreamSynchronize(s));
   hipEventRecord(c->ev[7], s);
   for (int i = 0; i < iters; ++i) TRY(once());
@@ -1919,6 +1980,12 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
   if (out_flops) *out_flops = flops;
   return TTASR_OK;
   });
+}
+
+int ttasr_bench_kernel_signature(ttasr_ctx* c, char* buf, int32_t len) {
+  if (!c || !buf || len < 1) return TTASR_E_INVALID;
+  snprintf(buf, (size_t)len, "%s", c->bench_sig.c_str());
+  return TTASR_OK;
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 // Replaces CTranslate2's MultiHeadAttention layer (un-vendored; arithmetic per HF modeling_whisper.py
 // :215-238, 241-356): q arrives pre-scaled by 1/8 (folded into the weights), softmax in f32.
 #include "common.hpp"
+#include <cstdio>
 
 // ------------------------------------------------------------------------------------------------
 // encoder attention, simple form.  Block = 4 waves = 16 queries of one (b, h); K/V tiles of 64 keys
@@ -153,7 +154,9 @@ template <> __device__ __forceinline__ void store_row<f16_t>(f16_t* p, const flo
 // over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
-thread_local int g_xattn_variant = 1;  // option xattn_nontemporal; default 1 = nontemporal K/V loads
+thread_local bool g_kernel_sig_on = false;
+thread_local char g_kernel_sig[192] = "";
+thread_local int g_xattn_variant = 3;  // bit 0: option xattn_nontemporal (nontemporal K/V loads), bit 1: option xattn_pipeline (software-pipelined form); default both
 using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 
 // Single pass, one memory round trip for pos <= 32*UNROLL cached keys: every lane keeps an online-softmax
@@ -364,9 +367,12 @@ template <typename T, bool NT> __device__ __forceinline__ void load_row(const T*
     RowVec<T>::load(p, v);
   }
 }
-template <typename T, bool PROBS, int NWV, int UNROLL, bool NT, bool QSLAB>
+// QMODE: where the query comes from - 0 the T rows `q`; 1 the K-split partial tiles of the q GEMM (`sq`); 2 (round-4 experiment,
+// VERDICT r3 next #1c) computed HERE from the LayerNorm output rows and this head's 64 rows of Wq behind the first K batch
+// (one launch less per layer; every workgroup re-reads its head's 164 KB of Wq through L2: measured in DESIGN.md 4.11).
+template <typename T, bool PROBS, int NWV, int UNROLL, bool NT, int QMODE>
 __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q, const T* K, const T* V, T* out, int H, int Tk,
-                                                                     int kv_div, const int* sel, float* probs, SlabIn sq) {
+                                                                     int kv_div, const int* sel, float* probs, SlabIn sq, QProj qp) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
   // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin): the K stream starts one round trip after launch
@@ -398,7 +404,47 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   // tiles): the stream starts one round trip after launch instead of two
   load_k(0);
   float qv[VEC];
-  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);  // q GEMM was K-split
+  if constexpr (QMODE == 1) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);  // q GEMM was K-split
+#ifdef TTASR_EXPERIMENTS
+  else if constexpr (QMODE == 2 && sizeof(T) == 2 && NWV == 4) {
+    // q[j] = round_T(bias[64 h + j] + sum_k x[b][k] * Wq[64 h + j][k]); wave w owns rows 16 w .. 16 w + 15, a lane owns the
+    // 16-byte chunks lane, lane + 64, lane + 128 of a row (d <= 1536); x chunks stay in registers, Wq rows arrive 8 at a time
+    qp.x = sgpr_pin_ptr(qp.x); qp.W = sgpr_pin_ptr(qp.W); qp.bias = sgpr_pin_ptr(qp.bias);
+    const int nch = d >> 3;
+    const u32x4_t* xp = (const u32x4_t*)((const T*)qp.x + (int64_t)b * d);
+    u32x4_t xv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const u32x4_t t = xp[min(lane + 64 * i, nch - 1)];
+      xv[i] = lane + 64 * i < nch ? t : u32x4_t{0u, 0u, 0u, 0u};   // chunks past the row multiply by zero
+    }
+    const u32x4_t* wp = (const u32x4_t*)((const T*)qp.W + (int64_t)(h * 64 + wave * 16) * d);
+    float* qs = part;   // [64] staging (the region is rewritten only after the last barrier of the kernel)
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+      u32x4_t wv[8][3];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wv[r][i] = wp[(int64_t)(r0 + r) * nch + min(lane + 64 * i, nch - 1)];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          s = N16<T>::dot2(wv[r][i].x, xv[i].x, s); s = N16<T>::dot2(wv[r][i].y, xv[i].y, s);
+          s = N16<T>::dot2(wv[r][i].z, xv[i].z, s); s = N16<T>::dot2(wv[r][i].w, xv[i].w, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) qs[wave * 16 + r0 + r] = s + qp.bias[h * 64 + wave * 16 + r0 + r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) qv[j] = to_f<T>(from_f<T>(qs[sub * VEC + j]));
+    __syncthreads();   // qs is inside `part`, which the epilogue rewrites - and sc[] must not be confused with it
+  }
+#endif
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
     if (it0 > 0) load_k(it0);
@@ -483,6 +529,135 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
     out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
   }
 }
+// Software-pipelined form of the kernel above (round 4; the decode step's kernel since then): the same row -> lane mapping, the
+// same per-lane accumulation order and the same reductions - BIT-IDENTICAL output - but two register sets per lane: batch i + 1
+// of the K (then V) stream is requested BEFORE batch i is scored, so a wave always has U to 2U KiB in flight instead of falling
+// to zero while it computes, and the first V batch is requested before the softmax.  Measured at B = 32 (640 workgroups on 256
+// CUs: 2.5 per CU), us per launch: non-pipelined 8 rows per batch 40.8; pipelined U = 8 41.5, 6 40.6, 5 40.4, 4 39.8, 3 39.5,
+// 2 43.8 (tools/microbench/xattn_bench.hip, profiles/r4_xattn_pipeline.txt).  At a balanced 2.97 workgroups per CU (B = 38) every
+// form runs 6.42-6.48 TB/s: the gain at B = 32 is a shorter tail of the uneven 3-vs-2 workgroup split, not a faster stream.
+// 16-bit storage, 4 waves, decode step only (no PROBS).
+template <typename T, bool NT, bool QSLAB, int U>
+__global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const T* K, const T* V, T* out, int H, int Tk, int kv_div,
+                                                              SlabIn sq) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int VEC = 8, LPR = 8, RPI = 8, NWV = 4;
+  extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
+  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out);
+  H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div);
+  sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
+  sq.ld = sgpr_pin(sq.ld);
+  const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = H * 64;
+  const int sub = lane % LPR, rin = lane / LPR;
+  float* part = sc + Tk;
+  float* red = part + NWV * 64;
+  const int bk = kv_div == 1 ? b : b / kv_div;
+  const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
+  const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
+  const int n_it = (Tk + NWV * RPI - 1) / (NWV * RPI);
+  // iteration `it` covers rows it * 32 .. + 31, wave w its rows 8 w .. 8 w + 7: the order of the kernel above (bit-identical).
+  // (Each wave streaming its own contiguous quarter of the frames instead measured 1.0 us slower: DESIGN.md 4.11.)
+  const int trow = wave * RPI + rin;
+  constexpr int TSTEP = NWV * RPI;
+  const int tend = Tk;
+  auto issue = [&](const T* base, int it0, u32x4_t (&r)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = min((it0 + u) * TSTEP + trow, Tk - 1);   // clamped, unconditional
+      if constexpr (NT) r[u] = __builtin_nontemporal_load((const u32x4_t*)(base + (int64_t)t * 64));
+      else r[u] = *(const u32x4_t*)(base + (int64_t)t * 64);
+    }
+  };
+  u32x4_t ra[U], rb[U];
+  issue(Kp, 0, ra);
+  float qv[VEC];
+  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
+  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  float mloc = -1e30f;
+  auto score = [&](int it0, const u32x4_t (&r)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (it0 + u) * TSTEP + trow;
+      float kf[VEC];
+      up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), kf);
+      float s = 0.f;
+      if (t < tend) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kf[j], s);
+      }
+      s = group_reduce<LPR>(s, OpSum{});
+      if (t < tend) {
+        if (sub == 0) sc[t] = s;
+        mloc = fmaxf(mloc, s);
+      }
+    }
+  };
+  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
+    if (it0 + U < n_it) issue(Kp, it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);   // the next batch is requested before this one is scored
+    score(it0, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + 2 * U < n_it) issue(Kp, it0 + 2 * U, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + U < n_it) score(it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  issue(Vp, 0, ra);   // V rows do not depend on the softmax: in flight under it
+  __builtin_amdgcn_sched_barrier(0);
+  mloc = wave_max(mloc);
+  if (lane == 0) red[wave] = mloc;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float lsum = 0.f;
+  for (int t = tid; t < Tk; t += NWV * 64) {
+    float p = __expf(sc[t] - mx);
+    sc[t] = p;
+    lsum += p;
+  }
+  lsum = wave_sum(lsum);
+  if (lane == 0) red[NWV + wave] = lsum;
+  __syncthreads();
+  const float denom = (red[4] + red[5]) + (red[6] + red[7]);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  auto accum = [&](int it0, const u32x4_t (&r)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = (it0 + u) * TSTEP + trow;
+      if (t < tend) {
+        float vf[VEC];
+        up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), vf);
+        const float p = sc[t];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+      }
+    }
+  };
+  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
+    if (it0 + U < n_it) issue(Vp, it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    accum(it0, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + 2 * U < n_it) issue(Vp, it0 + 2 * U, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + U < n_it) accum(it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
+  if (rin == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) part[wave * 64 + sub * VEC + j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
+  }
+}
+
 // Small batches (B*H workgroups < CU count: single-file transcription, beam rows of one clip, streaming): the
 // frames are split over gridDim.z workgroups per (b, h) (flash-decoding).  Each streams its slice of K then V
 // exactly like the kernel above and leaves {max, sum, unnormalised out[64]}; a one-wave-per-(b, h) kernel merges
@@ -754,8 +929,9 @@ int cross_attn_splits(int B, int H, int Tk) {
 
 template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
-                              float* split_ws, SlabIn sq, int ws_rows) {
-  if (ws_rows <= 0) ws_rows = B;  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
+                              float* split_ws, SlabIn sq, int ws_rows, QProj qp) {
+  if (ws_rows <= 0) ws_rows = B;
+  if (qp.W) split_ws = nullptr;   // in-kernel q projection (lab builds): the single-pass per-row kernel only (B * H >= 256, kv_div == 1)  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
   // many rows per clip (a long previous-text prompt in one prefill pass): the rows are the M dimension of an MFMA flash pass over
   // the clip's frames (kernels_flash.hip, CROSS) - K and V are streamed once per (clip, head, 128 rows)
   if constexpr (sizeof(T) == 2) {
@@ -801,13 +977,39 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
   // g_xattn_variant (option xattn_nontemporal, A/B testing): 1 = nontemporal K/V loads (default), 0 = plain.  (16 rows in flight per lane and
   // 8-wave workgroups were measured slower - DESIGN.md 4.11a - and are no longer instantiated.)
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 2 * 4);
+#ifdef TTASR_EXPERIMENTS   /* lab builds only: the in-kernel q projection (QMODE 2), measured slower - DESIGN.md 4.11 */
+#define TTASR_XA_QPROJ(NT_)                                                                                                            \
+  if constexpr (sizeof(T) == 2) {                                                                                                      \
+    if (qp.W) {                                                                                                                        \
+      hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 2>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,       \
+                         kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                                        \
+      return;                                                                                                                          \
+    }                                                                                                                                  \
+  }
+#else
+#define TTASR_XA_QPROJ(NT_)
+#endif
 #define TTASR_XA(NT_)                                                                                                                  \
   do {                                                                                                                                 \
-    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, true>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, \
-                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq);                                            \
-    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, false>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,  \
-                            kv_div, (const int*)nullptr, (float*)nullptr, sq);                                                         \
+    TTASR_XA_QPROJ(NT_)                                                                                                                \
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 1>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, \
+                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                        \
+    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 0>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,  \
+                            kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                                     \
   } while (0)
+  if constexpr (sizeof(T) == 2) {
+    if ((g_xattn_variant & 2) && !qp.W) {   // software-pipelined form (default since round 4), 3 rows per lane and batch
+#define TTASR_XP(NT_, QS_) hipLaunchKernelGGL((cross_attn_pipe_kernel<T, NT_, QS_, 3>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div, sq)
+      const bool nt = g_xattn_variant & 1, qs = sq.n > 0;
+      if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "cross_attn_pipe_kernel<%s, %s, %s, 3> grid %d", sig_type<T>(),
+                                    nt ? "true" : "false", qs ? "true" : "false", H * B * 256);
+      if (nt) { if (qs) TTASR_XP(true, true); else TTASR_XP(true, false); } else { if (qs) TTASR_XP(false, true); else TTASR_XP(false, false); }
+#undef TTASR_XP
+      return;
+    }
+  }
+  if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "cross_attn_decode_kernel<%s, false, 4, 8, %s, %d> grid %d", sig_type<T>(),
+                                (g_xattn_variant & 1) ? "true" : "false", sq.n > 0 ? 1 : 0, H * B * 256);
   if (g_xattn_variant & 1) TTASR_XA(true); else TTASR_XA(false);
 #undef TTASR_XA
 }
@@ -816,7 +1018,7 @@ template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel, float* probs,
                              hipStream_t s) {
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false, false>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{});
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false, 0>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{}, QProj{});
 }
 template void launch_cross_attn_probs<float>(const float*, const float*, const float*, float*, int, int, int, const int*, float*,
                                              hipStream_t);
@@ -825,8 +1027,8 @@ template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, cons
 template void launch_cross_attn_probs<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, const int*, float*,
                                               hipStream_t);
 template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*,
-                                              SlabIn, int);
+                                              SlabIn, int, QProj);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
-                                               float*, SlabIn, int);
+                                               float*, SlabIn, int, QProj);
 template void launch_cross_attn_decode<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, int, hipStream_t,
-                                               float*, SlabIn, int);
+                                               float*, SlabIn, int, QProj);

@@ -8,7 +8,9 @@
 //   gemm_bf16_fast  128x128x64 tile, global_load_lds (16 B) double-buffered staging, XOR-swizzled LDS
 //                   image (swizzle applied on the SOURCE address, guide rule 21), XCD-aware tile order.
 #include "common.hpp"
+#include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 
 // ------------------------------------------------------------------------------------------------
 // epilogue
@@ -634,6 +636,8 @@ static void launch_v3(const GemmArgs& g, hipStream_t s) {
     attr_done[dev & 63] = true;
   }
   const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+  if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "gemm_bf16_v3_kernel<%s, %d> grid %d", sig_type<T16>(), EPI,
+                                tiles_m * tiles_n * g.batch * 512);
   hipLaunchKernelGGL((gemm_bf16_v3_kernel<T16, EPI>), dim3(tiles_m * tiles_n, 1, g.batch), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
 }
 template <typename T16>
@@ -649,6 +653,229 @@ void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t s) {
 }
 template void launch_gemm_bf16_v3<bf16_t>(const GemmArgs&, hipStream_t);
 template void launch_gemm_bf16_v3<f16_t>(const GemmArgs&, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+// gemm_bf16_v4 (round 4): the v3 tile body as a PERSISTENT workgroup (one per CU) that walks its tiles, so that the part of
+// a tile that v3 leaves exposed at one workgroup per CU - the store-issue-bound epilogue, the workgroup relaunch and the
+// first stages' HBM/L2 latency - overlaps with neighbouring work:
+//   main loop of tile i  ->  bias of tile i+1 (waited for here: nothing else is in flight)  ->  LDS-DMA of stages 0..2 of tile
+//   i+1 (the ring is free: every fragment read of tile i was drained before the last barrier)  ->  epilogue of tile i (VALU +
+//   16 x 16-byte stores per lane, no LDS, no load)  ->  main loop of tile i+1, whose first two counted waits allow the 16 stores
+//   to be still in flight (vmcnt retires in issue order: [4 pieces of stage 2][16 stores][4 pieces of stage 3] ...).
+// Stores are unconditional with the row index clamped (rows past M replicate row M-1's operands, so they write row M-1's own
+// values again): the in-flight count the first waits rely on is then exact for every wave.
+// Same arithmetic as v3 (accumulation order, bias added after the loop, same conversions): bit-identical outputs.
+// EPI 0 (bias -> T), 1 (bias + GELU -> T), 8 (bias -> head-split T); batch == 1.
+// ------------------------------------------------------------------------------------------------
+template <typename T16, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, BK = 32;
+  constexpr int OP_BYTES = BM * BK * 2, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr bool ACT = EPI & 1, HS = EPI & 8;
+  static_assert((EPI & ~9) == 0, "v4 carries the T-output epilogues only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = tiles_m * tiles_n;
+  // static schedule: the workgroups that share an XCD (bid % 8) own one contiguous range of tiles and walk it round-robin
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this class
+  const int q = nwg >> 3, r = nwg & 7;
+  const int t_begin = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, t_end = t_begin + (xcd < r ? q + 1 : q);
+  const bf16_t* A = (const bf16_t*)g.A;
+  const bf16_t* W = (const bf16_t*)g.W;
+  const GemmEpi& e = g.epi;
+  const int srow = lane >> 2, sslot = lane & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t frag_off = (uint32_t)(fr * 64 + ((fq ^ v3_h((fr >> 2) & 3)) << 4));
+  const uint32_t a_off = lds_base + wm * 128 * 64 + frag_off;
+  const uint32_t w_off = lds_base + OP_BYTES + wn * 64 * 64 + frag_off;
+  const int nt = g.K / BK;  // >= 4
+  constexpr int GM = 4;
+
+  int m0 = 0, n0 = 0;
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+  auto place = [&](int tile) {   // tile -> (m0, n0), staging source pointers (same raster as v3)
+    const int band = tile / (GM * tiles_n);
+    const int rows_in_band = min(GM, tiles_m - band * GM);
+    const int in_band = tile - band * GM * tiles_n;
+    const int tn = in_band / rows_in_band;
+    const int tm = band * GM + (in_band - tn * rows_in_band);
+    m0 = tm * BM; n0 = tn * BN;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (wave * 2 + p) * 16 + srow;
+      const int chunk = sslot ^ v3_h((row >> 2) & 3);
+      a_src[p] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+      w_src[p] = W + (int64_t)(n0 + row) * g.ldw + chunk * 8;
+    }
+  };
+#define V4_STAGE(slot_, k0_)                                                                   \
+  do {                                                                                         \
+    char* base_ = smem + (slot_) * STAGE_BYTES;                                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                            \
+      glds16(a_src[p] + (k0_), base_ + (wave * 2 + p) * 1024);                                 \
+      glds16(w_src[p] + (k0_), base_ + OP_BYTES + (wave * 2 + p) * 1024);                      \
+    }                                                                                          \
+  } while (0)
+  auto load_bias = [&](float4 (&b4)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = *(const float4*)(e.bias + n0 + wn * 64 + fq * 4 + j * 16);   // bias != nullptr (gemm_bf16_v4_ok)
+    // waited for HERE, while nothing else is in flight: no later use of these registers may drain the LDS-DMA queue
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b4[0].x), "+v"(b4[0].y), "+v"(b4[0].z), "+v"(b4[0].w), "+v"(b4[1].x), "+v"(b4[1].y),
+                 "+v"(b4[1].z), "+v"(b4[1].w), "+v"(b4[2].x), "+v"(b4[2].y), "+v"(b4[2].z), "+v"(b4[2].w), "+v"(b4[3].x),
+                 "+v"(b4[3].y), "+v"(b4[3].z), "+v"(b4[3].w));
+  };
+
+  int tile = t_begin + slot;
+  if (tile >= t_end) return;
+  place(tile);
+  float4 bias4[4];
+  load_bias(bias4);
+  V4_STAGE(0, 0);
+  V4_STAGE(1, BK);
+  V4_STAGE(2, 2 * BK);
+  bool carry = false;   // 16 stores of the previous tile's epilogue sit behind the three prefetched stages
+
+  for (;;) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stages 0 and 1 landed (own pieces); queue behind them: stage 2 (4) [+ 16 stores]
+    if (carry) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind
+    for (int t = 0; t < nt; ++t) {
+      // ---- phase A ----
+      if (t + 2 < nt) {
+        // own pieces of stage t + 1 landed; queue behind them: stage t + 2 (4), and for t < 2 of a carried tile the 16 stores
+        // (t = 0: [stage 2][stores]; t = 1: [stores][stage 3] - from t = 2 on the stores are older than what is waited for)
+        if (carry && t < 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < nt) V4_STAGE((t + 3) & 3, (t + 3) * BK);
+      s16x8 a[8], b[4];
+      const uint32_t so = (uint32_t)((t & 3) * STAGE_BYTES);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(w_off + so + j * 16 * 64));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(a_off + so + i * 16 * 64));
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                     "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B ----
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every fragment read of this tile is drained
+    // ---- this tile's output coordinates (before the staging pointers move on) ----
+    const int nbase = n0 + wn * 64 + fq * 4;
+    int64_t coloff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + j * 16;
+      if (HS) {
+        const int which = n / e.hs_d, nn = n - which * e.hs_d;
+        coloff[j] = (int64_t)which * e.hs_which + (int64_t)(nn >> 6) * e.hs_T * 64 + (nn & 63);
+      } else coloff[j] = n;
+    }
+    const int mrow0 = m0 + wm * 128 + fr;
+    // ---- next tile: bias (waited for now), then its first three stages into the free ring ----
+    const int next = tile + per_xcd;
+    const bool has_next = next < t_end;
+    float4 bias_next[4];
+    if (has_next) {
+      place(next);
+      load_bias(bias_next);
+      V4_STAGE(0, 0);
+      V4_STAGE(1, BK);
+      V4_STAGE(2, 2 * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue of this tile: VALU + 16 unconditional 16-byte stores per lane ----
+    const bool odd = (fq & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = min(mrow0 + i * 16, g.M - 1);
+      int64_t rowoff;
+      if (HS) {
+        const int bb = m / e.hs_T, tt = m - bb * e.hs_T;
+        rowoff = ((int64_t)bb * e.hs_H * e.hs_T + tt) * 64;
+      } else rowoff = (int64_t)m * e.ldc;
+      uint2 pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j];
+        v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
+        if (ACT) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
+        }
+        pk[j].x = N16<T16>::pk(v[0], v[1]);
+        pk[j].y = N16<T16>::pk(v[2], v[3]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 4; jp += 2) {
+        auto sx = __builtin_amdgcn_permlane16_swap(pk[jp].x, pk[jp + 1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane16_swap(pk[jp].y, pk[jp + 1].y, false, false);
+        const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const int jj = odd ? jp + 1 : jp;
+        *(uint4*)((bf16_t*)e.out_t + rowoff + coloff[jj] - (odd ? 4 : 0)) = w;
+      }
+    }
+    if (!has_next) break;
+    tile = next;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = bias_next[j];
+    carry = true;
+  }
+#undef V4_STAGE
+}
+
+bool gemm_bf16_v4_ok(const GemmArgs& g) {
+  const int code = v3_epi_code(g.epi);
+  return (code == 0 || code == 1 || code == 8) && g.batch <= 1 && g.epi.bias != nullptr && gemm_bf16_v3_ok(g);
+}
+static int g_v4_cus[64] = {0};
+template <typename T16, int EPI>
+static void launch_v4(const GemmArgs& g, hipStream_t s) {
+  static bool attr_done[64] = {false};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
+    hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<T16, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    attr_done[dev & 63] = true;
+  }
+  if (!g_v4_cus[dev & 63]) {
+    hipDeviceProp_t p;
+    g_v4_cus[dev & 63] = hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256;
+  }
+  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+  const int grid = std::min(tiles_m * tiles_n, g_v4_cus[dev & 63]);
+  if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "gemm_bf16_v4_kernel<%s, %d> grid %d", sig_type<T16>(), EPI, grid * 512);
+  hipLaunchKernelGGL((gemm_bf16_v4_kernel<T16, EPI>), dim3(grid), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
+}
+template <typename T16>
+void launch_gemm_bf16_v4(const GemmArgs& g, hipStream_t s) {
+  switch (v3_epi_code(g.epi)) {
+    case 0: launch_v4<T16, 0>(g, s); break;
+    case 1: launch_v4<T16, 1>(g, s); break;
+    case 8: launch_v4<T16, 8>(g, s); break;
+    default: break;
+  }
+}
+template void launch_gemm_bf16_v4<bf16_t>(const GemmArgs&, hipStream_t);
+template void launch_gemm_bf16_v4<f16_t>(const GemmArgs&, hipStream_t);
 
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
   return g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.M >= 1 &&

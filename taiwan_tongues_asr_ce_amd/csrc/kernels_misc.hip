@@ -352,7 +352,9 @@ void launch_layernorm_rows(const float* x, const float* gamma, const float* beta
   else if (pre.n_slab <= 2) hipLaunchKernelGGL((layernorm_rows_kernel<T, 2, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 4) hipLaunchKernelGGL((layernorm_rows_kernel<T, 4, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 8) hipLaunchKernelGGL((layernorm_rows_kernel<T, 8, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
-  else hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab <= 16) hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
+  else if (pre.n_slab <= 20) hipLaunchKernelGGL((layernorm_rows_kernel<T, 20, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);  // per-head slabs (kernels_fused.hip)
+  else { fprintf(stderr, "ttasr: layernorm_rows sums at most 20 slabs (got %d)\n", pre.n_slab); abort(); }
 }
 template void launch_layernorm_rows<float>(const float*, const float*, const float*, float*, int, int, const LnPre&, hipStream_t);
 template void launch_layernorm_rows<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, const LnPre&, hipStream_t);

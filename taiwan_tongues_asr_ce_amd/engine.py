@@ -316,7 +316,9 @@ class Engine:
         ms, by, fl = C.c_float(), C.c_double(), C.c_double()
         self._check(self.lib.ttasr_bench_kernel(self.h, name.encode(), B, iters, C.byref(ms), C.byref(by), C.byref(fl)),
                     f"bench_kernel({name})")
-        return dict(ms=ms.value, bytes=by.value, flops=fl.value)
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.ttasr_bench_kernel_signature(self.h, buf, 256), "bench_kernel_signature")
+        return dict(ms=ms.value, bytes=by.value, flops=fl.value, signature=buf.value.decode())
 
     def sync(self):
         self._check(self.lib.ttasr_sync(self.h), "sync")

@@ -346,3 +346,31 @@ def test_every_set_option_key_is_documented_in_the_header():
     doc = hdr[hdr.index("kernel-selection overrides"):hdr.index("int ttasr_set_option")]
     documented = set(re.findall(r'"([a-z_0-9]+)"', doc))
     assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+
+
+def test_bench_reports_pmc_numbers_only_for_the_kernel_signature_they_were_taken_on():
+    """a committed counter profile is quoted by bench.py only when it lists the signature (kernel name,
+    template arguments, grid) of the kernel the run launched; a stale profile yields null plus a reason."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sig = "cross_attn_pipe_kernel<unsigned short, true, true, 3> grid 163840"
+    xp = {"kernel": "cross_attn_pipe_kernel grid 163840", "signatures": [sig], "traffic_bytes_per_32row_launch": 246679059}
+    tr, note = bench.xattn_traffic_from_profile(xp, sig, 32)
+    assert tr == 246679059 and sig in note
+    assert bench.xattn_traffic_from_profile(xp, sig, 16)[0] == round(246679059 / 2)
+    tr, note = bench.xattn_traffic_from_profile(xp, "cross_attn_decode_kernel<unsigned short, false, 4, 8, true, 1> grid 163840", 32)
+    assert tr is None and note.startswith("stale profile")
+    old = {"kernel": "cross_attn_decode_kernel grid 163840", "traffic_bytes_per_32row_launch": 1}   # a round-3 file: no signatures
+    assert bench.xattn_traffic_from_profile(old, sig, 32)[0] is None
+    g0, g1 = "gemm_bf16_v3_kernel<unsigned short, 0> grid 1443840", "gemm_bf16_v3_kernel<unsigned short, 1> grid 1925120"
+    kern = {"a": {"signatures": [g0], "mfma_busy_frac": 0.5}, "b": {"signatures": [g1], "mfma_busy_frac": 0.25}}
+    busy, note = bench.pmc_busy_from_profile(kern, [g0, g1], [1.0, 1.0])
+    assert note is None and abs(busy - 2.0 / (1 / 0.5 + 1 / 0.25)) < 1e-4
+    busy, note = bench.pmc_busy_from_profile(kern, [g0, "gemm_bf16_v4_kernel<unsigned short, 1> grid 1"], [1.0, 1.0])
+    assert busy is None and "stale profile" in note
+    # the committed profile must carry signatures (refreshed whenever the dominant kernel changes)
+    import json
+    xp_now = json.load(open(os.path.join(ROOT, "profiles", "xattn_pmc.json")))
+    assert xp_now.get("signatures"), "profiles/xattn_pmc.json predates the signature check: refresh it (tools/gpu_session.sh)"
