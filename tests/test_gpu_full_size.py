@@ -110,20 +110,38 @@ def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full)
     mel = np.stack([R.log_mel(clips[b], e.dims.n_mels) for b in rows])
     total, solo_total = Graded(), Graded()
     from oracle_checks import prompt_state
+    # the four rows go through the oracle as ONE batch of 4 (the 3.6 GB of decoder weights are read once per position instead of
+    # once per position and row; round 4: 103 s -> ~45 s of host time); row k's slice of the batched state serves its own gradings
+    enc_all = R.encoder_forward(torch.from_numpy(mel), Wb, rd)
+    start_all = prompt_state(prompt, enc_all, Wb, rd)
+
+    def row_state(k):
+        xkv, cache, last, per_pos = start_all
+        xk = [tuple(t[k:k + 1] for t in layer) for layer in xkv]
+        ck = R.SelfCache([t[k:k + 1] for t in cache.k], [t[k:k + 1] for t in cache.v])
+        return xk, ck, last[k:k + 1], [p[k:k + 1] for p in per_pos]
     for k, b in enumerate(rows):
-        enc_ref = R.encoder_forward(torch.from_numpy(mel[k:k + 1]), Wb, rd)
-        start = prompt_state(prompt, enc_ref, Wb, rd)                    # once per clip: shared by the three gradings below
-        for t, lg, want in zip(prompt, step_logits, start[3]):
-            assert float(np.abs(lg[b] - want[0].numpy()).max()) < 0.08, (b, t)
-        total.add(teacher_forced([res.tokens[b]], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16, n_check=4, start=start))
+        for t, lg, want in zip(prompt, step_logits, start_all[3]):
+            assert float(np.abs(lg[b] - want[k].numpy()).max()) < 0.08, (b, t)
+    total.add(teacher_forced([res.tokens[b] for b in rows], prompt, enc_all, Wb, rd, rules, tol=0.15, margin=0.16, n_check=4,
+                             start=start_all))
+    for k, b in enumerate(rows):
         if b in (5, 17):   # the same clip alone, greedy and beam(1)
             e.log_mel([clips[b]], want_output=False)
             e.encode(1)
             solo = e.generate([prompt], e.gen_opts(4, False)).tokens[0]
-            beam1 = e.generate_beam([prompt], 1, e.gen_opts(4, False)).tokens[0]
-            solo_total.add(teacher_forced([solo], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16, start=start))
-            solo_total.add(teacher_forced([[t for t in beam1 if t != st.eot]], prompt, enc_ref, Wb, rd, rules, tol=0.15, margin=0.16,
-                                          start=start))
+            beam1 = [t for t in e.generate_beam([prompt], 1, e.gen_opts(4, False)).tokens[0] if t != st.eot]
+            start = row_state(k)
+            n_both = min(len(solo), len(beam1))
+            if n_both == len(solo) == len(beam1):   # the usual case: both routes graded in one batched pass of the oracle
+                enc2 = torch.cat([enc_all[k:k + 1]] * 2)
+                st2 = ([tuple(torch.cat([t, t]) for t in layer) for layer in start[0]],
+                       R.SelfCache([torch.cat([t, t]) for t in start[1].k], [torch.cat([t, t]) for t in start[1].v]),
+                       torch.cat([start[2]] * 2), None)
+                solo_total.add(teacher_forced([solo, beam1], prompt, enc2, Wb, rd, rules, tol=0.15, margin=0.16, start=st2))
+            else:
+                solo_total.add(teacher_forced([solo], prompt, enc_all[k:k + 1], Wb, rd, rules, tol=0.15, margin=0.16, start=start))
+                solo_total.add(teacher_forced([beam1], prompt, enc_all[k:k + 1], Wb, rd, rules, tol=0.15, margin=0.16, start=start))
     e.log_mel(clips, want_output=False)                                   # leave the module engine with the batch resident
     e.encode(B)
     assert total.n_steps == 16 and total.n_clear >= 8, total              # not vacuous: most steps carried a clear margin
