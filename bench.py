@@ -79,7 +79,7 @@ def cpu_baseline(dims, n_new: int, budget_layers: int = 2, budget_steps: int = 6
     total = (t_mel + t_stem + dims.enc_layers * t_layer + dims.dec_layers * t_xkv
              + n_steps * (dims.dec_layers * t_dec_layer + t_vocab))
     return {"value": round(30.0 / total, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": (f"oracle/whisper_ref.py (torch CPU f32, {cores} threads), 1 clip of the same workload: log-mel + "
+            "sample": (f"EXTRAPOLATED from a bounded sample (the one complete run is `full_run_cached`): oracle/whisper_ref.py (torch CPU f32, {cores} threads), 1 clip of the same workload: log-mel + "
                        f"stem + {L}/{dims.enc_layers} encoder layers, cross-KV and {budget_steps} decode steps of "
                        f"{L}/{dims.dec_layers} decoder layers at large-v3 width, scaled linearly to full depth and "
                        f"{n_steps} steps; est. {total:.1f} s per 30-s clip. The reference's own CPU path "

@@ -1,962 +1,7 @@
-// libttasr host side: context, weight intake, workspaces, the encode / decode schedules and the C ABI
-// declared in include/ttasr.h.  One context = one GPU = one HIP stream; no hidden CPU fallback: every
-// compute entry point launches the HIP kernels of this directory or fails with an error code.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <algorithm>
-#include <atomic>
-#include <map>
-#include <memory>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "../../include/ttasr.h"
-#include "common.hpp"
-
-namespace {
-
-thread_local std::string g_create_error;
-
-struct Slot {              // where one named tensor lands on the device
-  void* dst = nullptr;     // T* (matrix kinds) or float* (vector kinds)
-  int64_t rows = 0, cols = 0;
-  int kind = 0;            // 0 matrix->T, 1 vector->f32, 2 conv [out][in][3] -> T [out][3][in], 3 f32 matrix
-  float scale = 1.0f;
-  bool loaded = false;
-  void* sh_base = nullptr;  // bf16 mode, decoder matrices: fragment-packed copy for the skinny GEMM
-  int sh_row_off = 0;
-};
-
-struct EncLayerW { float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *b1, *b2; void *wqkv, *wo, *w1, *w2; };
-struct DecLayerW {
-  float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *bqx, *bkvx, *box, *ln3g, *ln3b, *b1, *b2;
-  void *wqkv, *wo, *wqx, *wkvx, *wox, *w1, *w2;
-  void *wqkv_sh = nullptr, *wo_sh = nullptr, *wqx_sh = nullptr, *wox_sh = nullptr, *w1_sh = nullptr, *w2_sh = nullptr;
-};
-
-}  // namespace
-
-struct ttasr_ctx {
-  ttasr_config cfg{};
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t cur = nullptr;      // stream the schedule helpers enqueue on
-  std::string err;
-  bool lowp = false;   // 16-bit storage mode (bf16 or fp16 weights / activations, f32 accumulate / LayerNorm / softmax)
-  bool f16 = false;    // ... and the 16-bit format is IEEE fp16 (TTASR_COMPUTE_F16) instead of bf16
-  bool finalized = false;
-  bool force_basic = false;
-  bool use_graph = true;
-  size_t esz = 4;  // sizeof(T)
-  int T = 0, F = 0, d = 0, H = 0, ffn = 0, V = 0, ldv = 0, M = 0, maxB = 0, n_samples = 0;
-  int pages_per_seq = 0;
-  std::vector<void*> allocs;
-  struct Pool { char* base = nullptr; size_t cap = 0, used = 0; } small_pool, big_pool;  // bump arenas (see dalloc)
-  size_t arena_hint = 0;   // rough device footprint of this context (bytes): picks the big-arena chunk size
-  std::unordered_map<std::string, Slot> slots;
-
-  // weights
-  void *conv1_w = nullptr, *conv2_w = nullptr, *emb = nullptr, *dpos = nullptr, *emb_sh = nullptr;
-  float *conv1_b = nullptr, *conv2_b = nullptr, *epos = nullptr, *elnf_g = nullptr, *elnf_b = nullptr, *dlnf_g = nullptr,
-        *dlnf_b = nullptr;
-  std::vector<EncLayerW> enc;
-  std::vector<DecLayerW> dec;
-  float* stage_f32 = nullptr;  // upload staging (destination layout, f32)
-  float* stage_raw = nullptr;  // host uploads land here first (source layout)
-  size_t stage_elems = 0;
-
-  // mel constants
-  float *filters = nullptr, *dcos = nullptr, *dsin = nullptr, *window = nullptr;
-
-  // workspaces
-  float* pcm_dev = nullptr; int64_t* nsamp_dev = nullptr; unsigned* clip_max = nullptr; int64_t* mel_geom = nullptr;
-  float* mel = nullptr; void* mel_t = nullptr; void* c1 = nullptr;
-  float* x = nullptr; void *h = nullptr, *qkv = nullptr, *att = nullptr, *mid = nullptr, *enc_out = nullptr;
-  void* xkv = nullptr; int64_t xkv_layer_elems = 0, xkv_which_elems = 0;
-  // option xkv_fp8 (opt-in serving mode, kernels_fp8.hip): an e4m3 copy of the cross-KV cache (same element strides, one byte per
-  // value) + one f32 scale per (layer, K | V, clip, head); read by the decode step's cross-attention only
-  bool xkv_fp8 = false, xkv8_valid = false; uint8_t* xkv8 = nullptr; float* xkv8_scale = nullptr;
-  void* pool = nullptr; int64_t pool_layer_elems = 0; int32_t* page_table = nullptr;
-  float* xsplit_ws = nullptr;  // split-frame cross-attention (small batches)
-  float* dx = nullptr; void *dh = nullptr, *dqkv = nullptr, *dq = nullptr, *datt = nullptr, *dmid = nullptr; float* logits = nullptr;
-  float* rows_out = nullptr;
-  int kv_div = 1;            // rows per clip sharing one cross-KV (beam width); 1 for greedy
-  int identity_pages = 1;    // page_table is the identity map (greedy): the self-attention kernel computes page ids
-  int32_t* pairs_dev = nullptr;  // beam search: copy-on-write page pairs
-  float* topk_lp = nullptr; int32_t* topk_id = nullptr; int32_t* row_state = nullptr;  // beam search scratch
-#ifdef TTASR_EXPERIMENTS
-  int skip_mask = 0;  // TTASR_SKIP (experiment builds only): 1 LN, 2 decode GEMMs, 4 self-attn, 8 cross-attn, 16 select
-#else
-  static constexpr int skip_mask = 0;  // release builds cannot drop work from the decode step
-#endif
-  float* slab = nullptr;      // [16][maxB][3d] f32 partial tiles of the K-split decode GEMMs (bf16 mode)
-  int ks_want[4] = {0, 0, 0, 0};  // option ksplit_out / _q / _qkv / _fc2: K slices of the out-proj / q / qkv / fc2 decode GEMMs (0 = automatic, 1 = unsplit)
-  int gemm_force = 0;         // option enc_gemm = 1|2|3|4 (A/B testing of the encoder GEMM kernels)
-  bool gemm_persistent = true;   // option enc_gemm_persistent [1]: the persistent 256x256 GEMM where a workgroup has >= 2 tiles (round 4: encoder + cross-KV 92.6 -> 89.1 ms, bit-identical)
-  bool vocab_persistent = true;  // option vocab_persistent = 0: the one-workgroup-per-32-outputs kernel for the vocabulary projection (A/B)
-  bool no_flash = false;      // option flash = 0
-  int prefill_ns_min = 2;     // option prefill_ns_min: shortest prompt (positions before the last) whose <|startoftranscript|> position is taken
-                              // from the prefill pass.  Round 3: 2 (was 16) - the small prefill pass now runs the decode-step launch plan
-                              // (K-split GEMMs), so 3 prompt positions x 32 clips cost 6.4 ms against 8.8 ms as three steps
-  bool enc_res_epilogue = false;  // option enc_residual_epilogue: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
-  DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
-  RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
-  int32_t* pinned_i32 = nullptr;  // host pinned scratch
-  int max_new_alloc = 0, max_prompt_alloc = 0;
-
-  int B_mel = 0, B_enc = 0, B_dec = 0;
-  std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
-  int xattn_nt = 1, xattn_pipe = 1, weights_nt = 1;  // options xattn_nontemporal / xattn_pipeline / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
-  bool multi_step = true;   // option multi_step_graph = 0: one graph replay per decode step (A/B testing)
-  bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)
-  bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)
-  bool prefill_tiled = false;  // option prefill_tiled: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
-  hipEvent_t ev[8]{};
-  std::string bench_sig;     // signature of the kernel the last ttasr_bench_kernel call launched (ttasr_bench_kernel_signature)
-  float phase_ms[4]{0, 0, 0, 0};
-  // option enc_kernel_timing: one hipEvent after every launch of run_encoder / run_cross_kv, so the NEXT ttasr_encode also
-  // reports where the phase went, in situ (class sums: ttasr_encoder_kernel_ms).  Off in the timed benchmark steps.
-  bool enc_timing = false;
-  std::vector<hipEvent_t> enc_ev;
-  std::vector<int> enc_ev_class;
-  float enc_class_ms[8]{0, 0, 0, 0, 0, 0, 0, 0};
-
-  // decode-step graphs keyed by (B, with_logits)
-  struct GraphKey { int B; int mode; int variant; hipGraphExec_t exec; };
-  std::vector<GraphKey> graphs;   // least recently used first
-  static constexpr size_t kMaxGraphs = 16;
-  RuleParams rp{};
-};
-
-namespace {
-
-int fail(ttasr_ctx* c, int code, const char* fmt, ...) {
-  char buf[1024];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c) c->err = buf; else g_create_error = buf;
-  return code;
-}
-
-#define HIPCHK(c, call)                                                                                       \
-  do {                                                                                                        \
-    hipError_t e_ = (call);                                                                                   \
-    if (e_ != hipSuccess) return fail((c), TTASR_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
-                                      __FILE__, __LINE__);                                                    \
-  } while (0)
-
-// Device memory comes from a few large arenas, not one hipMalloc per tensor: the decode step is ~350 dependent launches
-// whose first access is to a small, rarely touched buffer (LayerNorm gamma / beta, a bias, the residual rows).  With ~2500
-// separate allocations every one of those sat on its own page, and after the ~10 GB a step streams (weights + cross-KV)
-// each launch opened with an address-translation miss.  The small pool (< 1 MiB requests: every vector, every decode
-// activation) is one 64 MiB block that stays translation- and cache-resident; matrices and KV pools come from 1 GiB+
-// blocks that the driver can map with its largest page fragments.
-template <typename P>
-int dalloc(ttasr_ctx* c, P** p, size_t bytes, bool zero = true) {
-  if (bytes == 0) bytes = 16;
-  bytes = (bytes + 255) & ~(size_t)255;
-  ttasr_ctx::Pool& pool = bytes < (1u << 20) ? c->small_pool : c->big_pool;
-  // big chunks: 1 GiB for real models; small geometries (tests, streaming-size engines) open 64 MiB chunks instead of pinning a
-  // gigabyte each - the hint is the footprint ttasr_create estimated for this context
-  const size_t big_chunk = c->arena_hint >= ((size_t)1 << 30) ? (size_t)1 << 30 : (size_t)64 << 20;
-  const size_t chunk = &pool == &c->small_pool ? (size_t)64 << 20 : big_chunk;
-  if (bytes > chunk / 2) {
-    // an oversize request gets its own allocation and leaves the active chunk (and its unused tail) in service
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    c->allocs.push_back(q);
-    if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
-    *p = (P*)q;
-    return 0;
-  }
-  if (pool.used + bytes > pool.cap) {
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, chunk);
-    if (e != hipSuccess) return fail(c, TTASR_E_NOMEM, "hipMalloc(%zu) failed: %s", chunk, hipGetErrorString(e));
-    c->allocs.push_back(q);
-    pool.base = (char*)q; pool.cap = chunk; pool.used = 0;
-  }
-  void* q = pool.base + pool.used;
-  pool.used += bytes;
-  if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
-  *p = (P*)q;
-  return 0;
-}
-#define TRY(expr) do { int rc_ = (expr); if (rc_ != 0) return rc_; } while (0)
-// Run CALL with T = the context's storage type (float | bf16_t | f16_t)
-#define TT_DISPATCH(c_, CALL)                                   \
-  do {                                                          \
-    if (!(c_)->lowp) { using T = float; CALL; }                 \
-    else if ((c_)->f16) { using T = f16_t; CALL; }              \
-    else { using T = bf16_t; CALL; }                            \
-  } while (0)
-
-// slaney mel filter bank, same construction as the oracle's mel_filter_bank (float64, cast to f32)
-double hz2mel(double f) {
-  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
-  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
-}
-double mel2hz(double m) {
-  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
-  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
-}
-std::vector<float> mel_filters(int n_mels) {
-  const int nf = 201;
-  std::vector<double> hz(n_mels + 2);
-  const double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
-  for (int i = 0; i < n_mels + 2; ++i) hz[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
-  std::vector<float> fb((size_t)nf * n_mels);
-  for (int k = 0; k < nf; ++k) {
-    double f = 8000.0 * k / (nf - 1);
-    for (int m = 0; m < n_mels; ++m) {
-      double down = -(hz[m] - f) / (hz[m + 1] - hz[m]);
-      double up = (hz[m + 2] - f) / (hz[m + 2] - hz[m + 1]);
-      double w = std::max(0.0, std::min(down, up)) * 2.0 / (hz[m + 2] - hz[m]);
-      fb[(size_t)k * n_mels + m] = (float)w;
-    }
-  }
-  return fb;
-}
-
-void add_slot(ttasr_ctx* c, const std::string& name, void* dst, int64_t rows, int64_t cols, int kind, float scale = 1.f) {
-  Slot s; s.dst = dst; s.rows = rows; s.cols = cols; s.kind = kind; s.scale = scale;
-  c->slots[name] = s;
-}
-
-int alloc_mat(ttasr_ctx* c, void** p, int64_t elems) { return dalloc(c, (char**)p, (size_t)elems * c->esz); }
-int alloc_vec(ttasr_ctx* c, float** p, int64_t elems) { return dalloc(c, p, (size_t)elems * 4); }
-
-int build_weights(ttasr_ctx* c) {
-  const int d = c->d, F = c->ffn, M = c->M, V = c->V;
-  const size_t e = c->esz;
-  auto off = [&](void* base, int64_t elems) { return (void*)((char*)base + (size_t)elems * e); };
-  TRY(alloc_mat(c, &c->conv1_w, (int64_t)d * 3 * M)); TRY(alloc_vec(c, &c->conv1_b, d));
-  TRY(alloc_mat(c, &c->conv2_w, (int64_t)d * 3 * d)); TRY(alloc_vec(c, &c->conv2_b, d));
-  TRY(alloc_vec(c, &c->epos, (int64_t)c->T * d));
-  add_slot(c, "model.encoder.conv1.weight", c->conv1_w, d, 3 * M, 2);
-  add_slot(c, "model.encoder.conv1.bias", c->conv1_b, d, 1, 1);
-  add_slot(c, "model.encoder.conv2.weight", c->conv2_w, d, 3 * d, 2);
-  add_slot(c, "model.encoder.conv2.bias", c->conv2_b, d, 1, 1);
-  add_slot(c, "model.encoder.embed_positions.weight", c->epos, c->T, d, 3);
-  auto ln = [&](const std::string& p, float** g, float** b) -> int {
-    TRY(alloc_vec(c, g, d)); TRY(alloc_vec(c, b, d));
-    add_slot(c, p + ".weight", *g, d, 1, 1); add_slot(c, p + ".bias", *b, d, 1, 1);
-    return 0;
-  };
-  // fused q|k|v: rows [0,d) = q (pre-scaled by head_dim^-0.5 = 1/8, exact in f32 and bf16;
-  // HF modeling_whisper.py:309 scales the q_proj output), [d,2d) = k (no bias, :279), [2d,3d) = v
-  auto attn_fused = [&](const std::string& p, void** wqkv, float** bqkv) -> int {
-    TRY(alloc_mat(c, wqkv, (int64_t)3 * d * d)); TRY(alloc_vec(c, bqkv, 3 * d));
-    add_slot(c, p + ".q_proj.weight", *wqkv, d, d, 0, 0.125f);
-    add_slot(c, p + ".q_proj.bias", *bqkv, d, 1, 1, 0.125f);
-    add_slot(c, p + ".k_proj.weight", off(*wqkv, (int64_t)d * d), d, d, 0);
-    add_slot(c, p + ".v_proj.weight", off(*wqkv, (int64_t)2 * d * d), d, d, 0);
-    add_slot(c, p + ".v_proj.bias", *bqkv + 2 * d, d, 1, 1);
-    return 0;
-  };
-  auto lin = [&](const std::string& p, void** w, float** b, int64_t n_out, int64_t n_in) -> int {
-    TRY(alloc_mat(c, w, n_out * n_in)); TRY(alloc_vec(c, b, n_out));
-    add_slot(c, p + ".weight", *w, n_out, n_in, 0); add_slot(c, p + ".bias", *b, n_out, 1, 1);
-    return 0;
-  };
-  c->enc.resize(c->cfg.enc_layers);
-  for (int i = 0; i < c->cfg.enc_layers; ++i) {
-    std::string p = "model.encoder.layers." + std::to_string(i);
-    EncLayerW& L = c->enc[i];
-    TRY(ln(p + ".self_attn_layer_norm", &L.ln1g, &L.ln1b));
-    TRY(attn_fused(p + ".self_attn", &L.wqkv, &L.bqkv));
-    TRY(lin(p + ".self_attn.out_proj", &L.wo, &L.bo, d, d));
-    TRY(ln(p + ".final_layer_norm", &L.ln2g, &L.ln2b));
-    TRY(lin(p + ".fc1", &L.w1, &L.b1, F, d));
-    TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
-  }
-  TRY(ln("model.encoder.layer_norm", &c->elnf_g, &c->elnf_b));
-  TRY(alloc_mat(c, &c->emb, (int64_t)V * d));
-  TRY(alloc_mat(c, &c->dpos, (int64_t)c->cfg.n_text_ctx * d));
-  add_slot(c, "model.decoder.embed_tokens.weight", c->emb, V, d, 0);
-  add_slot(c, "model.decoder.embed_positions.weight", c->dpos, c->cfg.n_text_ctx, d, 0);
-  c->dec.resize(c->cfg.dec_layers);
-  for (int i = 0; i < c->cfg.dec_layers; ++i) {
-    std::string p = "model.decoder.layers." + std::to_string(i);
-    DecLayerW& L = c->dec[i];
-    TRY(ln(p + ".self_attn_layer_norm", &L.ln1g, &L.ln1b));
-    TRY(attn_fused(p + ".self_attn", &L.wqkv, &L.bqkv));
-    TRY(lin(p + ".self_attn.out_proj", &L.wo, &L.bo, d, d));
-    TRY(ln(p + ".encoder_attn_layer_norm", &L.ln2g, &L.ln2b));
-    TRY(alloc_mat(c, &L.wqx, (int64_t)d * d)); TRY(alloc_vec(c, &L.bqx, d));
-    add_slot(c, p + ".encoder_attn.q_proj.weight", L.wqx, d, d, 0, 0.125f);
-    add_slot(c, p + ".encoder_attn.q_proj.bias", L.bqx, d, 1, 1, 0.125f);
-    TRY(alloc_mat(c, &L.wkvx, (int64_t)2 * d * d)); TRY(alloc_vec(c, &L.bkvx, 2 * d));
-    add_slot(c, p + ".encoder_attn.k_proj.weight", L.wkvx, d, d, 0);
-    add_slot(c, p + ".encoder_attn.v_proj.weight", off(L.wkvx, (int64_t)d * d), d, d, 0);
-    add_slot(c, p + ".encoder_attn.v_proj.bias", L.bkvx + d, d, 1, 1);
-    TRY(lin(p + ".encoder_attn.out_proj", &L.wox, &L.box, d, d));
-    TRY(ln(p + ".final_layer_norm", &L.ln3g, &L.ln3b));
-    TRY(lin(p + ".fc1", &L.w1, &L.b1, F, d));
-    TRY(lin(p + ".fc2", &L.w2, &L.b2, d, F));
-  }
-  TRY(ln("model.decoder.layer_norm", &c->dlnf_g, &c->dlnf_b));
-  if (c->lowp) {  // fragment-packed copies of every matrix the decode step streams
-    auto packed = [&](const std::string& name, void** base, int64_t rows_total, int64_t K, int row_off) -> int {
-      if (!*base) TRY(alloc_mat(c, base, (rows_total + 31) / 32 * 32 * K));
-      Slot& s = c->slots[name];
-      s.sh_base = *base; s.sh_row_off = row_off;
-      return 0;
-    };
-    TRY(packed("model.decoder.embed_tokens.weight", &c->emb_sh, V, d, 0));
-    for (int i = 0; i < c->cfg.dec_layers; ++i) {
-      std::string p = "model.decoder.layers." + std::to_string(i);
-      DecLayerW& L = c->dec[i];
-      TRY(packed(p + ".self_attn.q_proj.weight", &L.wqkv_sh, 3 * d, d, 0));
-      TRY(packed(p + ".self_attn.k_proj.weight", &L.wqkv_sh, 3 * d, d, d));
-      TRY(packed(p + ".self_attn.v_proj.weight", &L.wqkv_sh, 3 * d, d, 2 * d));
-      TRY(packed(p + ".self_attn.out_proj.weight", &L.wo_sh, d, d, 0));
-      TRY(packed(p + ".encoder_attn.q_proj.weight", &L.wqx_sh, d, d, 0));
-      TRY(packed(p + ".encoder_attn.out_proj.weight", &L.wox_sh, d, d, 0));
-      TRY(packed(p + ".fc1.weight", &L.w1_sh, F, d, 0));
-      TRY(packed(p + ".fc2.weight", &L.w2_sh, d, F, 0));
-    }
-  }
-  c->stage_elems = 0;   // every host upload is staged in the source layout: the largest registered tensor decides
-  for (auto& kv : c->slots) c->stage_elems = std::max<size_t>(c->stage_elems, (size_t)(kv.second.rows * kv.second.cols));
-  TRY(dalloc(c, &c->stage_f32, c->stage_elems * 4, false));
-  TRY(dalloc(c, &c->stage_raw, c->stage_elems * 4, false));
-  return 0;
-}
-
-int build_workspaces(ttasr_ctx* c) {
-  const int64_t B = c->maxB, T = c->T, F = c->F, d = c->d, M = c->M, H = c->H;
-  TRY(dalloc(c, &c->pcm_dev, (size_t)B * (c->n_samples + 512) * 4));  // + context samples of file windows
-  TRY(dalloc(c, &c->mel_geom, (size_t)B * 3 * 8));
-  TRY(dalloc(c, &c->nsamp_dev, (size_t)B * 8));
-  TRY(dalloc(c, &c->clip_max, (size_t)B * 4));
-  TRY(dalloc(c, &c->mel, (size_t)B * M * F * 4));
-  TRY(alloc_mat(c, &c->mel_t, B * (F + 2) * M));
-  TRY(alloc_mat(c, &c->c1, B * (F + 2) * d));
-  TRY(dalloc(c, &c->x, (size_t)B * T * d * 4));
-  TRY(alloc_mat(c, &c->h, B * T * d));
-  TRY(alloc_mat(c, &c->qkv, B * T * 3 * d));
-  TRY(alloc_mat(c, &c->att, B * T * d));
-  TRY(alloc_mat(c, &c->mid, B * T * c->ffn));
-  TRY(alloc_mat(c, &c->enc_out, B * T * d));
-  c->xkv_which_elems = B * H * T * 64;
-  c->xkv_layer_elems = 2 * c->xkv_which_elems;
-  TRY(alloc_mat(c, &c->xkv, c->xkv_layer_elems * c->cfg.dec_layers));
-  TRY(dalloc(c, &c->xsplit_ws, (size_t)B * H * 8 * 66 * 4));
-  c->pages_per_seq = (c->cfg.n_text_ctx + 15) / 16;
-  const int64_t n_pages = B * c->pages_per_seq;
-  c->pool_layer_elems = n_pages * 2 * H * 16 * 64;
-  TRY(alloc_mat(c, &c->pool, c->pool_layer_elems * c->cfg.dec_layers));
-  TRY(dalloc(c, &c->page_table, (size_t)n_pages * 4));
-  std::vector<int32_t> pt(n_pages);
-  for (int64_t i = 0; i < n_pages; ++i) pt[i] = (int32_t)i;  // identity: row b owns pages [b*pps, (b+1)*pps)
-  HIPCHK(c, hipMemcpyAsync(c->page_table, pt.data(), n_pages * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  TRY(dalloc(c, &c->dx, (size_t)B * d * 4));
-  TRY(alloc_mat(c, &c->dh, B * d));
-  TRY(alloc_mat(c, &c->dqkv, B * 3 * d));
-  TRY(alloc_mat(c, &c->dq, B * d));
-  TRY(alloc_mat(c, &c->datt, B * d));
-  TRY(alloc_mat(c, &c->dmid, B * c->ffn));
-  TRY(dalloc(c, &c->logits, (size_t)B * c->ldv * 4));
-  TRY(dalloc(c, &c->slab, (size_t)16 * B * 3 * d * 4));
-  c->max_new_alloc = c->cfg.n_text_ctx;
-  c->max_prompt_alloc = c->cfg.n_text_ctx;
-  TRY(dalloc(c, &c->st.cur_tok, B * 4)); TRY(dalloc(c, &c->st.step, 16)); TRY(dalloc(c, &c->st.n_sampled, B * 4));
-  TRY(dalloc(c, &c->st.last_tok, B * 4)); TRY(dalloc(c, &c->st.pen_tok, B * 4)); TRY(dalloc(c, &c->st.last_ts, B * 4));
-  TRY(dalloc(c, &c->st.done, B * 4)); TRY(dalloc(c, &c->st.n_done, 16)); TRY(dalloc(c, &c->st.sum_logprob, B * 4));
-  TRY(dalloc(c, &c->st.no_speech, B * 4)); TRY(dalloc(c, &c->st.out_tokens, (size_t)B * c->max_new_alloc * 4));
-  TRY(dalloc(c, &c->prompt_dev, (size_t)B * c->max_prompt_alloc * 4)); TRY(dalloc(c, &c->plen_dev, B * 4));
-  TRY(dalloc(c, &c->mask_dev, (size_t)c->V + 16));
-  TRY(dalloc(c, &c->rule_dyn_dev, sizeof(RuleDyn)));
-  c->st.dyn = c->rule_dyn_dev;
-  TRY(dalloc(c, &c->pairs_dev, (size_t)B * 2 * 4));
-  TRY(dalloc(c, &c->topk_lp, (size_t)B * 8 * 4)); TRY(dalloc(c, &c->topk_id, (size_t)B * 8 * 4));
-  TRY(dalloc(c, &c->row_state, (size_t)B * 4 * 4));
-  c->st.mask = c->mask_dev;
-  HIPCHK(c, hipHostMalloc((void**)&c->pinned_i32, 4096));
-  // mel constants
-  std::vector<float> fb = mel_filters(c->M), cs(400), sn(400), wn(400);
-  for (int i = 0; i < 400; ++i) {
-    cs[i] = (float)std::cos(2.0 * M_PI * i / 400.0);
-    sn[i] = (float)std::sin(2.0 * M_PI * i / 400.0);
-    wn[i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / 400.0));
-  }
-  TRY(dalloc(c, &c->filters, fb.size() * 4)); TRY(dalloc(c, &c->dcos, 1600)); TRY(dalloc(c, &c->dsin, 1600));
-  TRY(dalloc(c, &c->window, 1600));
-  HIPCHK(c, hipMemcpyAsync(c->filters, fb.data(), fb.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->dcos, cs.data(), 1600, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->dsin, sn.data(), 1600, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->window, wn.data(), 1600, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (auto& e : c->ev) HIPCHK(c, hipEventCreate(&e));
-  return 0;
-}
-
-// ---- typed schedules ------------------------------------------------------------------------------
-template <typename T>
-void gemm(ttasr_ctx* c, const GemmArgs& g) {
-  if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && g.M >= 256) {
-      const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage, 4 = 3 as persistent workgroups
-      // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
-      // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
-      const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
-      // persistent form (round 4): pays once a workgroup has several tiles to walk (>= 2 per CU)
-      if ((v ? v == 4 : (c->gemm_persistent && tiles_v3 >= 512)) && gemm_bf16_v4_ok(g)) { launch_gemm_bf16_v4<T>(g, c->cur); return; }
-      if ((v ? v == 3 || v == 4 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3<T>(g, c->cur); return; }
-      if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2<T>(g, c->cur); return; }
-      if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast<T>(g, c->cur); return; }
-    }
-  }
-  launch_gemm_basic<T>(g, c->cur);
-}
-
-// decode-step GEMM: B rows against a streamed weight; bf16 uses the fragment-packed skinny kernel
-template <typename T>
-void dec_gemm(ttasr_ctx* c, const GemmArgs& g, const void* Wsh) {
-  if (c->skip_mask & 2) return;
-  if constexpr (sizeof(T) == 2) {
-    if (!c->force_basic && Wsh) {
-      // the vocabulary projection (f32 logits, nothing else in the epilogue): persistent workgroups, activation rows in registers
-      const GemmEpi& e = g.epi;
-      if (c->vocab_persistent && e.out_f32 && !e.out_t && !e.bias && !e.residual && e.act == 0 &&
-          launch_gemm_vocab<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, e.out_f32, e.ldc, c->cur, c->device)) return;
-      if (launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, c->cur)) return;
-    }
-  }
-  launch_gemm_basic<T>(g, c->cur);
-}
-
-template <typename T>
-GemmArgs lin_args(const void* A, const void* W, int M, int N, int K) {
-  GemmArgs g; g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.epi.ldc = N;
-  return g;
-}
-
-// in-situ kernel classes of the encoder phase (ttasr_encoder_kernel_ms)
-enum EncClass { EC_CONV = 0, EC_LN = 1, EC_QKV = 2, EC_ATTN = 3, EC_OUT = 4, EC_FC1 = 5, EC_FC2 = 6, EC_XKV = 7 };
-void enc_mark(ttasr_ctx* c, int cls) {   // cls < 0: the start mark
-  if (!c->enc_timing) return;
-  const size_t i = c->enc_ev_class.size();
-  if (i >= c->enc_ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c->enc_ev.push_back(e); }
-  hipEventRecord(c->enc_ev[i], c->cur);
-  c->enc_ev_class.push_back(cls);
-}
-
-template <typename T>
-int run_cross_kv(ttasr_ctx* c, int B) {
-  const int d = c->d, T_ = c->T;
-  for (int l = 0; l < c->cfg.dec_layers; ++l) {
-    GemmArgs g = lin_args<T>(c->enc_out, c->dec[l].wkvx, B * T_, 2 * d, d);
-    g.epi.bias = c->dec[l].bkvx;
-    g.epi.out_t = (char*)c->xkv + (size_t)l * c->xkv_layer_elems * c->esz;
-    g.epi.headsplit = 1; g.epi.hs_T = T_; g.epi.hs_H = c->H; g.epi.hs_d = d; g.epi.hs_which = c->xkv_which_elems;
-    gemm<T>(c, g);
-    if constexpr (sizeof(T) == 2) {
-      if (c->xkv_fp8 && c->xkv8) {   // quantise this layer's K and V blocks of the B clips (one workgroup per (clip, head) block)
-        for (int which = 0; which < 2; ++which) {
-          const int64_t off = (int64_t)l * c->xkv_layer_elems + which * c->xkv_which_elems;
-          launch_xkv_quant<T>((const T*)c->xkv + off, c->xkv8 + off, c->xkv8_scale + ((size_t)l * 2 + which) * c->maxB * c->H,
-                              (int64_t)B * c->H, T_, c->cur);
-        }
-      }
-    }
-    enc_mark(c, EC_XKV);
-  }
-  c->xkv8_valid = c->xkv_fp8 && c->xkv8 != nullptr && sizeof(T) == 2;
-  return 0;
-}
-
-template <typename T>
-int run_encoder(ttasr_ctx* c, int B) {
-  const int d = c->d, T_ = c->T, F = c->F, M = c->M, ffn = c->ffn;
-  hipStream_t s = c->cur;
-  hipEventRecord(c->ev[2], s);
-  c->enc_ev_class.clear();
-  enc_mark(c, -1);
-  {  // conv1 as GEMM over the zero-padded time-major mel image: row t of A = rows t..t+2 of the image
-    GemmArgs g; g.A = c->mel_t; g.W = c->conv1_w; g.M = F; g.N = d; g.K = 3 * M; g.lda = M; g.ldw = 3 * M;
-    g.batch = B; g.batch_stride_a = (int64_t)(F + 2) * M;
-    g.epi.bias = c->conv1_b; g.epi.act = 1; g.epi.out_t = (char*)c->c1 + (size_t)d * c->esz; g.epi.ldc = d;
-    g.epi.batch_stride_c = (int64_t)(F + 2) * d;
-    gemm<T>(c, g);
-  }
-  {  // conv2 (stride 2): row t of A starts at padded row 2t; epilogue adds the sinusoid positions
-    GemmArgs g; g.A = c->c1; g.W = c->conv2_w; g.M = T_; g.N = d; g.K = 3 * d; g.lda = 2 * d; g.ldw = 3 * d;
-    g.batch = B; g.batch_stride_a = (int64_t)(F + 2) * d;
-    g.epi.bias = c->conv2_b; g.epi.act = 1; g.epi.rowtab = c->epos; g.epi.rowmod = T_; g.epi.out_f32 = c->x;
-    g.epi.ldc = d; g.epi.batch_stride_c = (int64_t)T_ * d;
-    gemm<T>(c, g);
-    enc_mark(c, EC_CONV);
-  }
-  const int R = B * T_;
-  // bf16 mode: the out-proj / fc2 GEMMs write their result (bias added) as a T "delta" into the h buffer (dead at that
-  // point: its consumer GEMM has run) with the plain wide-store epilogue, and the LayerNorm that follows adds it to the
-  // f32 residual stream while normalising (kernels_misc.hip layernorm_kernel ADD).  The f32 residual read-modify-write in
-  // those GEMMs' epilogues - exposed at one workgroup per CU - was what held out-proj at 0.66 PF/s.
-  // f32 parity mode keeps the residual epilogue.
-  const bool delta = sizeof(T) == 2 && !c->force_basic && !c->enc_res_epilogue;
-  bool pending = false;  // a delta sits in h and has not been added to x yet
-  auto ln = [&](const float* g_, const float* b_, void* out) {
-    if (pending) launch_layernorm_add<T>(c->x, (const T*)c->h, g_, b_, (T*)out, R, d, s);
-    else launch_layernorm<T>(c->x, g_, b_, (T*)out, R, d, s);
-    pending = false;
-    enc_mark(c, EC_LN);
-  };
-  auto residual_gemm = [&](const void* A, const void* W, const float* bias, int K, int cls) {
-    GemmArgs g = lin_args<T>(A, W, R, d, K); g.epi.bias = bias;
-    if (delta) { g.epi.out_t = c->h; pending = true; }
-    else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
-    gemm<T>(c, g);
-    enc_mark(c, cls);
-  };
-  for (int l = 0; l < c->cfg.enc_layers; ++l) {
-    const EncLayerW& L = c->enc[l];
-    ln(L.ln1g, L.ln1b, c->h);
-    { GemmArgs g = lin_args<T>(c->h, L.wqkv, R, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = c->qkv; gemm<T>(c, g); }
-    enc_mark(c, EC_QKV);
-    bool flash = false;
-    if constexpr (sizeof(T) == 2) {
-      if (!c->force_basic && !c->no_flash) { launch_enc_attn_flash_bf16<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s); flash = true; }
-    }
-    if (!flash) launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
-    enc_mark(c, EC_ATTN);
-    residual_gemm(c->att, L.wo, L.bo, d, EC_OUT);
-    ln(L.ln2g, L.ln2b, c->h);
-    { GemmArgs g = lin_args<T>(c->h, L.w1, R, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->mid; gemm<T>(c, g); }
-    enc_mark(c, EC_FC1);
-    residual_gemm(c->mid, L.w2, L.b2, ffn, EC_FC2);
-  }
-  ln(c->elnf_g, c->elnf_b, c->enc_out);
-  hipEventRecord(c->ev[3], s);
-  run_cross_kv<T>(c, B);
-  hipEventRecord(c->ev[4], s);
-  return 0;
-}
-
-// One decoder step for rows [row0, row0 + n) at position *st.step, enqueued on c->cur.
-// mode 0: through logits + select; 1: logits only (test API / beam search); 2: no logits (all rows forced by
-// the prompt), select just advances the forced token.  `total_rows` = rows of the whole step (both half-batch chains):
-// the select launch that finishes last advances the position counter.
-//
-// bf16 launch plan per layer (the measured mode; no float atomics anywhere, every launch bit-reproducible):
-//   LN1 -> qkv GEMM (K-split, f32 slabs) -> self-attention (sums the q, k, v slabs) -> out-proj (K-split slabs) ->
-//   LN2 (x += bias + slabs, then normalise) -> q GEMM (K-split slabs) -> cross-attention (sums the q slabs) ->
-//   out-proj (slabs) -> LN3 (sums) -> fc1 + GELU (unsplit: the activation needs the full sum) -> fc2 (slabs) -> next LN1 (sums)
-// Splitting K spreads every weight matrix over >= 160 workgroups in pieces of <= 20-40 KB (a CU takes in only ~25 GB/s
-// of HBM-cold bytes).  LN1 of layer 0 creates the row from the token + position embedding itself.
-// The f32 parity mode runs the generic kernels: LayerNorm, gemm_basic with the residual epilogue in place.
-template <typename T>
-void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
-  const int d = c->d, ffn = c->ffn;
-  hipStream_t s = c->cur;
-  const size_t e = c->esz;
-  auto tp = [&](void* base, int64_t width) { return (void*)((char*)base + (size_t)row0 * width * e); };  // T rows
-  float* dx = c->dx + (size_t)row0 * d;
-  void *dh = tp(c->dh, d), *dqkv = tp(c->dqkv, 3 * d), *dq = tp(c->dq, d), *datt = tp(c->datt, d), *dmid = tp(c->dmid, ffn);
-  float* logits = c->logits + (size_t)row0 * c->ldv;
-  const bool skinny = sizeof(T) == 2 && !c->force_basic;
-  float* slab_base = c->slab;
-  // K slices per GEMM kind (0 out-proj, 1 q, 2 qkv, 3 fc2); attention consumers sum at most 4 slabs
-  auto slices = [&](int kind, int N, int K) {
-    if (!skinny) return 1;
-    int want = c->ks_want[kind];
-    // qkv (N = 3 d: already 3x the workgroups of the other GEMMs): 2 slices measured best (5.35 vs 6.02 us at large-v3) - with ONE
-    // 32-row group; wider batches (beam search, streaming: 33-128 rows) keep the automatic choice, whose k-steps per wave fit the
-    // straight-line form (2 slices there meant the looped form: 10.4 us at 40 rows)
-    if (kind == 2 && want == 0 && n <= 32 && (N + 31) / 32 >= 96) want = 2;
-    int ks = gemm_skinny_ksplit(n, N, K, want);
-    if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
-    return ks;
-  };
-  // what the next LayerNorm still has to add to the residual rows (K-split residual GEMM) or to create (embedding)
-  struct { const float* bias = nullptr; int n_slab = 0; bool embed = true; } pend;
-
-  // K-split GEMM into slabs [ks][maxB rows][N]; returns the slab descriptor for the consumer (n == 0: not split, `g` ran whole)
-  auto split_gemm = [&](const GemmArgs& g, const void* Wsh, const float* bias, int ks) -> SlabIn {
-    SlabIn si;
-    if constexpr (sizeof(T) == 2) {
-      if (ks > 1 && Wsh) {
-        GemmEpi ep; ep.ldc = g.N;
-        float* slab = slab_base;  // rows are local to this chain's region: [ks][maxB][N]
-        const int64_t stride = (int64_t)c->maxB * g.N;
-        if (launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, n, g.N, g.K, ep, s, ks, slab, stride)) {
-          si.slab = slab; si.bias = bias; si.n = ks; si.stride = stride; si.ld = g.N;
-        }
-      }
-    }
-    return si;
-  };
-  // x += W a + b
-  auto residual_gemm = [&](const void* A, const void* W, const void* Wsh, const float* bias, int K, int kind) {
-    if (c->skip_mask & 2) return;
-    GemmArgs g = lin_args<T>(A, W, n, d, K);
-    const SlabIn si = split_gemm(g, Wsh, bias, slices(kind, d, K));
-    if (si.n) { pend.bias = bias; pend.n_slab = si.n; return; }
-    g.epi.bias = bias; g.epi.residual = dx; g.epi.out_f32 = dx;
-    dec_gemm<T>(c, g, Wsh);
-  };
-  auto ln = [&](const float* g_, const float* b_) {
-    if (c->skip_mask & 1) return;
-    LnPre pre;
-    pre.x_out = dx;
-    if (pend.embed) { pre.tok = c->st.cur_tok + row0; pre.step = c->st.step; pre.emb = c->emb; pre.pos = c->dpos; }
-    else if (pend.n_slab) { pre.bias = pend.bias; pre.slab = slab_base; pre.n_slab = pend.n_slab; pre.slab_stride = (int64_t)c->maxB * d; }
-    launch_layernorm_rows<T>(dx, g_, b_, (T*)dh, n, d, pre, s);
-    pend.bias = nullptr; pend.n_slab = 0; pend.embed = false;
-  };
-  for (int l = 0; l < c->cfg.dec_layers; ++l) {
-    const DecLayerW& L = c->dec[l];
-    ln(L.ln1g, L.ln1b);
-    SlabIn sqkv;
-    { GemmArgs g = lin_args<T>(dh, L.wqkv, n, 3 * d, d);
-      sqkv = split_gemm(g, L.wqkv_sh, L.bqkv, slices(2, 3 * d, d));
-      if (!sqkv.n) { g.epi.bias = L.bqkv; g.epi.out_t = dqkv; dec_gemm<T>(c, g, L.wqkv_sh); } }
-    if (!(c->skip_mask & 4))
-      launch_self_attn_decode<T>((const T*)dqkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
-                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s, sqkv);
-    residual_gemm(datt, L.wo, L.wo_sh, L.bo, d, 0);
-    ln(L.ln2g, L.ln2b);
-    SlabIn sq;
-    { GemmArgs g = lin_args<T>(dh, L.wqx, n, d, d);
-      sq = split_gemm(g, L.wqx_sh, L.bqx, slices(1, d, d));
-      if (!sq.n) { g.epi.bias = L.bqx; g.epi.out_t = dq; dec_gemm<T>(c, g, L.wqx_sh); } }
-    // cross-KV of clip (row / kv_div); a half-batch offset is only used with kv_div == 1
-    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems + (int64_t)(row0 / c->kv_div) * c->H * c->T * 64;
-    bool fp8_done = false;
-    if constexpr (sizeof(T) == 2) {   // opt-in: the e4m3 copy of the cache, unshared rows that fill the chip (the single-pass kernel's case)
-      if (c->xkv_fp8 && c->xkv8_valid && c->kv_div == 1 && n * c->H >= 256 && skinny && !(c->skip_mask & 8)) {
-        const int64_t off = (int64_t)l * c->xkv_layer_elems + (int64_t)row0 * c->H * c->T * 64;
-        const float* ksc = c->xkv8_scale + ((size_t)l * 2) * c->maxB * c->H + (size_t)row0 * c->H;
-        fp8_done = launch_cross_attn_fp8<T>((const T*)dq, c->xkv8 + off, c->xkv8 + off + c->xkv_which_elems, ksc, ksc + (size_t)c->maxB * c->H,
-                                            (T*)datt, n, c->H, c->T, s, sq);
-      }
-    }
-    if (!fp8_done && !(c->skip_mask & 8))
-      launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq, c->maxB - row0);
-    residual_gemm(datt, L.wox, L.wox_sh, L.box, d, 0);
-    ln(L.ln3g, L.ln3b);
-    { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; dec_gemm<T>(c, g, L.w1_sh); }
-    residual_gemm(dmid, L.w2, L.w2_sh, L.b2, ffn, 3);
-  }
-  if (mode != 2) {
-    ln(c->dlnf_g, c->dlnf_b);
-    GemmArgs g = lin_args<T>(dh, c->emb, n, c->V, d);  // proj_out tied to embed_tokens (modeling_whisper.py:965)
-    g.epi.out_f32 = logits; g.epi.ldc = c->ldv;
-    dec_gemm<T>(c, g, c->emb_sh);
-  }
-  if (mode != 1 && !(c->skip_mask & 16)) {
-    DecState st = c->st;  // row-offset view of the search state
-    st.cur_tok += row0; st.n_sampled += row0; st.last_tok += row0; st.pen_tok += row0; st.last_ts += row0; st.done += row0;
-    st.sum_logprob += row0; st.no_speech += row0; st.out_tokens += (size_t)row0 * c->rp.max_new;
-    if (st.prompt) { st.prompt += (size_t)row0 * c->rp.max_prompt; st.prompt_len += row0; }
-    launch_select(logits, st, c->rp, n, nullptr, s, c->st.step + 1, total_rows);
-  }
-}
-
-// Batched prompt prefill: positions 0..npos-1 of n_seq sequences in ONE pass (rows [sequence][position]) instead of
-// npos token-by-token steps.  Only the self-attention K/V of those positions has to survive (no logits: every one of
-// these positions is followed by another forced prompt token), so the pass borrows the encoder's activation
-// workspaces, which are idle once the cross-KV is built.  Sequence s attends to the cross-KV of clip s / seq_per_clip.
-// GEMMs go through the encoder dispatch (M = n_seq * npos rows; 256x256 MFMA tiles once M >= 256).
-// Alignment variant (ttasr_align): one sequence of clip `al->clip`; the cross-attention rows of the selected
-// (layer, head) pairs are written to al->probs, and the residual stream is left in c->x for the token log-probs.
-struct AlignOut {
-  int clip;
-  const int* sel;   // device [dec_layers][H]: index into probs or -1
-  float* probs;     // device [n_sel][npos][T]
-};
-template <typename T>
-void run_prefill(ttasr_ctx* c, int n_seq, int npos, int seq_per_clip, int max_prompt, const AlignOut* al = nullptr) {
-  const int d = c->d, ffn = c->ffn, n = n_seq * npos;
-  hipStream_t s = c->cur = c->stream;
-  float* x = c->x;
-  void *h = c->h, *qkv = c->qkv, *att = c->att, *mid = c->mid;
-  launch_embed_prefill<T>(c->prompt_dev, max_prompt, 1, n_seq, npos, (const T*)c->emb, (const T*)c->dpos, x, d, s);
-  // up to 128 rows (short prompts: a handful of positions x the clips of a pass) the fragment-packed decode GEMM streams each
-  // weight once for all rows; beyond that the rows are a real M dimension for the tiled encoder GEMMs
-  const bool small = n <= 128 && !c->force_basic && !c->prefill_tiled;
-  // Round 3: the small pass runs the DECODE-STEP launch plan - every GEMM whose consumer can add partial results is cut into K
-  // slices (160-320 workgroups instead of 40 of them pulling 164-656 KB each: a CU takes in ~25 GB/s of cold bytes), the
-  // partial tiles go to the f32 slabs, and the per-row LayerNorm / the cross-attention kernel sum them in slab order (no
-  // atomics: bit-reproducible).  A 3-position prompt of 32 clips then costs about 1.3 decode steps instead of 3.
-  const bool slabbed = small && sizeof(T) == 2;
-  const int64_t slab_cap = (int64_t)16 * c->maxB * 3 * d;   // floats in c->slab
-  struct { const float* bias = nullptr; int n_slab = 0; int64_t stride = 0; } pend;
-  auto pgemm = [&](const GemmArgs& g, const void* Wsh) {
-    if constexpr (sizeof(T) == 2) {
-      if (small && Wsh && launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, g.M, g.N, g.K, g.epi, s)) return;
-    }
-    gemm<T>(c, g);
-  };
-  // K-split GEMM into slabs [ks][n][N]; returns the slab descriptor (n == 0: not split, the caller runs the GEMM whole)
-  auto split_gemm = [&](const GemmArgs& g, const void* Wsh, const float* bias, int max_ks) -> SlabIn {
-    SlabIn si;
-    if constexpr (sizeof(T) == 2) {
-      if (slabbed && Wsh) {
-        int ks = gemm_skinny_ksplit(n, g.N, g.K, 0);
-        if (ks > max_ks) ks = gemm_skinny_ksplit(n, g.N, g.K, max_ks);
-        const int64_t stride = (int64_t)n * g.N;
-        GemmEpi ep; ep.ldc = g.N;
-        if (ks > 1 && ks * stride <= slab_cap &&
-            launch_gemm_skinny<T>((const T*)Wsh, (const T*)g.A, n, g.N, g.K, ep, s, ks, c->slab, stride)) {
-          si.slab = c->slab; si.bias = bias; si.n = ks; si.stride = stride; si.ld = g.N;
-        }
-      }
-    }
-    return si;
-  };
-  auto ln = [&](const float* g_, const float* b_) {
-    if (slabbed) {
-      LnPre pre; pre.x_out = x;
-      if (pend.n_slab) { pre.bias = pend.bias; pre.slab = c->slab; pre.n_slab = pend.n_slab; pre.slab_stride = pend.stride; }
-      launch_layernorm_rows<T>(x, g_, b_, (T*)h, n, d, pre, s);
-      pend.bias = nullptr; pend.n_slab = 0;
-    } else {
-      launch_layernorm<T>(x, g_, b_, (T*)h, n, d, s);
-    }
-  };
-  auto residual_gemm = [&](const void* A, const void* W, const void* Wsh, const float* bias, int K) {   // x += W a + b
-    GemmArgs g = lin_args<T>(A, W, n, d, K);
-    const SlabIn si = split_gemm(g, Wsh, bias, 16);
-    if (si.n) { pend.bias = bias; pend.n_slab = si.n; pend.stride = si.stride; return; }
-    g.epi.bias = bias; g.epi.residual = x; g.epi.out_f32 = x;
-    pgemm(g, Wsh);
-  };
-  for (int l = 0; l < c->cfg.dec_layers; ++l) {
-    const DecLayerW& L = c->dec[l];
-    ln(L.ln1g, L.ln1b);
-    { GemmArgs g = lin_args<T>(h, L.wqkv, n, 3 * d, d); g.epi.bias = L.bqkv; g.epi.out_t = qkv; pgemm(g, L.wqkv_sh); }
-    launch_self_attn_prefill<T>((const T*)qkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
-                                c->identity_pages, (T*)att, n_seq, npos, c->H, s);
-    residual_gemm(att, L.wo, L.wo_sh, L.bo, d);
-    ln(L.ln2g, L.ln2b);
-    SlabIn sq;   // the query of the cross-attention: K-split too when its consumer can sum slabs (not the alignment pass)
-    { GemmArgs g = lin_args<T>(h, L.wqx, n, d, d);
-      if (!al && npos * seq_per_clip < 32) sq = split_gemm(g, L.wqx_sh, L.bqx, 4);   // >= 32 rows per clip: the MFMA flash pass reads T rows
-      if (!sq.n) { g.epi.bias = L.bqx; g.epi.out_t = qkv; pgemm(g, L.wqx_sh); } }  // q reuses the qkv buffer
-    const T* Kx = (const T*)c->xkv + (int64_t)l * c->xkv_layer_elems;
-    if (al) {
-      const T* Kc = Kx + (int64_t)al->clip * c->H * c->T * 64;
-      launch_cross_attn_probs<T>((const T*)qkv, Kc, Kc + c->xkv_which_elems, (T*)att, n, c->H, c->T, al->sel + (size_t)l * c->H,
-                                 al->probs, s);
-    } else {
-      launch_cross_attn_decode<T>((const T*)qkv, Kx, Kx + c->xkv_which_elems, (T*)att, n, c->H, c->T, npos * seq_per_clip, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws, sq, c->maxB);
-    }
-    residual_gemm(att, L.wox, L.wox_sh, L.box, d);
-    ln(L.ln3g, L.ln3b);
-    { GemmArgs g = lin_args<T>(h, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = mid; pgemm(g, L.w1_sh); }
-    residual_gemm(mid, L.w2, L.w2_sh, L.b2, ffn);
-  }
-  // callers read the finished residual rows from c->x (no-speech probability, token log-probs of the alignment pass): fold the
-  // last fc2's partial tiles in (the final decoder LayerNorm does it; its normalised output lands in h and is not used here)
-  if (pend.n_slab) ln(c->dlnf_g, c->dlnf_b);
-}
-
-// How many leading prompt positions can be prefilled: every row must still have a forced token after them and the rows
-// must fit the borrowed encoder workspaces.  Below 2 positions the pass does not pay.  `ns_from_prefill` = the caller can
-// take the no-speech probability from the prefilled <|startoftranscript|> position (prefill_no_speech); otherwise that
-// position needs a real decode step and bounds the prefill.
-int prefill_positions(const ttasr_ctx* c, int min_plen, const ttasr_gen_opts* o, bool ns_from_prefill = false) {
-  if (c->no_prefill) return 0;
-  int p = min_plen - 1;
-  if (o->no_speech >= 0 && !ns_from_prefill) p = std::min(p, o->sot_index);
-  p = std::min(p, c->cfg.n_audio_ctx);
-  return p >= 2 ? p : 0;
-}
-
-// No-speech probability from a prefill pass: the residual rows of position `sot` of every sequence (left in c->x by
-// run_prefill, rows [sequence][position]) -> final LayerNorm -> vocabulary projection -> softmax(raw logits)[no_speech].
-template <typename T>
-int prefill_no_speech(ttasr_ctx* c, int n_seq, int npos, int sot, int no_speech_tok) {
-  hipStream_t s = c->stream;
-  const int d = c->d;
-  c->cur = s;
-  HIPCHK(c, hipMemcpy2DAsync(c->dx, (size_t)d * 4, c->x + (size_t)sot * d, (size_t)npos * d * 4, (size_t)d * 4, n_seq,
-                             hipMemcpyDeviceToDevice, s));
-  launch_layernorm_rows<T>(c->dx, c->dlnf_g, c->dlnf_b, (T*)c->dh, n_seq, d, LnPre{}, s);
-  GemmArgs g = lin_args<T>(c->dh, c->emb, n_seq, c->V, d);
-  g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-  dec_gemm<T>(c, g, c->emb_sh);
-  launch_token_prob(c->logits, c->ldv, c->V, no_speech_tok, c->st.no_speech, n_seq, s);
-  return 0;
-}
-
-// One decode step = one dependent chain of ~355 launches on the context's stream, captured as a hipGraph.  Splitting the
-// batch into two half-batch chains on two streams inside the graph (round 1's dual-chain experiment: +4 % then) doubles the
-// launch count and, with the round-2 kernels, measures 3 % SLOWER (3.15 vs 3.05 ms per step): removed.
-template <typename T>
-void run_decode_step(ttasr_ctx* c, int B, int mode) {
-  c->cur = c->stream;
-  run_decode_rows<T>(c, 0, B, mode, B);
-  // modes 0 and 2 end with select_kernel, whose last workgroup advances the position; mode 1 has no select
-  if (mode == 1 || (c->skip_mask & 16)) launch_advance(c->st.step, c->stream);
-}
-
-// `nsteps` consecutive steps of the same mode as ONE graph (round 4): the search state is device-resident, so a run of greedy
-// steps between two host polls needs no host involvement at all; one replay instead of nsteps saves the graph-launch gap
-// (~8 us on the device, 10-16 us of host time per replay) per step.
-int step_graph(ttasr_ctx* c, int B, int mode, int nsteps = 1) {
-  if (!c->use_graph) {
-    for (int i = 0; i < nsteps; ++i) TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
-    return 0;
-  }
-  const int variant = (c->kv_div * 2 + c->identity_pages) * 64 + nsteps;
-  for (size_t i = 0; i < c->graphs.size(); ++i) {
-    if (c->graphs[i].B == B && c->graphs[i].mode == mode && c->graphs[i].variant == variant) {
-      // most recently used at the back: the cache is bounded (the streaming micro-batcher varies B from 1 to max_batch rows)
-      if (i + 1 != c->graphs.size()) std::rotate(c->graphs.begin() + i, c->graphs.begin() + i + 1, c->graphs.end());
-      HIPCHK(c, hipGraphLaunch(c->graphs.back().exec, c->stream));
-      return 0;
-    }
-  }
-  hipGraph_t graph = nullptr;
-  HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < nsteps; ++i) TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
-  HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
-  hipGraphExec_t exec = nullptr;
-  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);   // on the failure path too
-  if (ie != hipSuccess) return fail(c, TTASR_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
-  if (c->graphs.size() >= ttasr_ctx::kMaxGraphs) {   // evict the least recently used executable
-    hipGraphExecDestroy(c->graphs.front().exec);
-    c->graphs.erase(c->graphs.begin());
-  }
-  c->graphs.push_back({B, mode, variant, exec});
-  HIPCHK(c, hipGraphLaunch(exec, c->stream));
-  return 0;
-}
-
-int check_ready(ttasr_ctx* c, int B) {
-  if (!c) return TTASR_E_INVALID;
-  if (!c->finalized) return fail(c, TTASR_E_INVALID, "weights not finalized (call ttasr_finalize_weights first)");
-  if (B < 1 || B > c->maxB) return fail(c, TTASR_E_INVALID, "batch %d outside [1, max_batch=%d]", B, c->maxB);
-  HIPCHK(c, hipSetDevice(c->device));
-  return 0;
-}
-
-int upload_rules(ttasr_ctx* c, const ttasr_gen_opts* o, int max_prompt) {
-  if (!o) return fail(c, TTASR_E_INVALID, "opts is NULL");
-  if (o->max_new_tokens < 1 || o->max_new_tokens > c->max_new_alloc)
-    return fail(c, TTASR_E_INVALID, "max_new_tokens %d outside [1, %d]", o->max_new_tokens, c->max_new_alloc);
-  std::vector<uint8_t> mask(c->V, 0);
-  for (int i = 0; i < o->n_suppress; ++i) {
-    int t = o->suppress[i];
-    if (t < 0 || t >= c->V) return fail(c, TTASR_E_INVALID, "suppress id %d outside vocabulary", t);
-    mask[t] |= 1;
-  }
-  for (int i = 0; i < o->n_begin_suppress; ++i) {
-    int t = o->begin_suppress[i];
-    if (t < 0 || t >= c->V) return fail(c, TTASR_E_INVALID, "begin_suppress id %d outside vocabulary", t);
-    mask[t] |= 2;
-  }
-  HIPCHK(c, hipMemcpyAsync(c->mask_dev, mask.data(), c->V, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  RuleParams& rp = c->rp;
-  rp.V = c->V; rp.ldv = c->ldv; rp.max_prompt = max_prompt; rp.max_new = o->max_new_tokens;
-  rp.eot = o->eot; rp.no_timestamps = o->no_timestamps; rp.timestamp_begin = o->timestamp_begin;
-  rp.no_speech = o->no_speech; rp.sot_index = o->sot_index; rp.timestamps = o->timestamps;
-  rp.max_initial = o->max_initial_timestamp_index; rp.suppress_eot = o->suppress_eot;
-  rp.temperature = 0.f; rp.seed = 0;
-  if (rp.eot < 0 || rp.eot >= c->V || rp.timestamp_begin < 0 || rp.timestamp_begin > c->V)
-    return fail(c, TTASR_E_INVALID, "special token ids outside vocabulary");
-  return 0;
-}
-
-void drop_rule_graphs(ttasr_ctx* c);
-// After the rules of a call are known: the per-window scalars go to device memory (stream-ordered in front of the decode
-// launches); the captured mode 0 / 2 graphs are dropped only when a BAKED scalar changed.
-int commit_rules(ttasr_ctx* c, const RuleParams& old) {
-  c->rule_dyn_host = RuleDyn{c->rp.max_prompt, c->rp.max_new, c->rp.sot_index, c->rp.seed};
-  HIPCHK(c, hipMemcpyAsync(c->rule_dyn_dev, &c->rule_dyn_host, sizeof(RuleDyn), hipMemcpyHostToDevice, c->stream));
-  RuleParams a = old;
-  a.max_prompt = c->rp.max_prompt; a.max_new = c->rp.max_new; a.sot_index = c->rp.sot_index; a.seed = c->rp.seed;
-  if (memcmp(&a, &c->rp, sizeof a) != 0) drop_rule_graphs(c);
-  return 0;
-}
-
-void drop_graphs(ttasr_ctx* c) {
-  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
-  c->graphs.clear();
-}
-// The rule scalars (RuleParams) are baked into the select launch of the mode 0 / 2 graphs only; the logits-only graphs
-// (mode 1: step API, beam search) never launch select_kernel and survive a change of rules - with
-// condition_on_previous_text the prompt geometry changes on nearly every window of a file.
-void drop_rule_graphs(ttasr_ctx* c) {
-  size_t k = 0;
-  for (auto& g : c->graphs) {
-    if (g.mode == 1) c->graphs[k++] = g; else hipGraphExecDestroy(g.exec);
-  }
-  c->graphs.resize(k);
-}
-
-// Kernel-selection overrides (ttasr_set_option).  Everything defaults to the measured configuration; an override changes
-// which kernels the captured decode graphs hold, so the graphs are dropped.
-int set_option(ttasr_ctx* c, const std::string& key, int v) {
-  const bool on = v != 0;
-  if (key == "enc_kernel_timing") { c->enc_timing = on; return 0; }   // measurement only: the captured decode graphs stay
-  if (key == "flash") c->no_flash = !on;
-  else if (key == "prefill") c->no_prefill = !on;
-  else if (key == "vocab_persistent") c->vocab_persistent = on;
-  else if (key == "xsplit") c->no_xsplit = !on;
-  else if (key == "graph") c->use_graph = on;
-  else if (key == "multi_step_graph") c->multi_step = on;
-  else if (key == "generic_kernels") c->force_basic = on;
-  else if (key == "prefill_tiled") c->prefill_tiled = on;
-  else if (key == "prefill_ns_min") { if (v < 0) return 1; c->prefill_ns_min = v; }
-  else if (key == "enc_residual_epilogue") c->enc_res_epilogue = on;
-  else if (key == "enc_gemm") { if (v < 0 || v > 4) return 1; c->gemm_force = v; }
-  else if (key == "enc_gemm_persistent") c->gemm_persistent = on;
-  else if (key == "ksplit_out") { if (v < 0 || v > 16) return 1; c->ks_want[0] = v; }
-  else if (key == "ksplit_q") { if (v < 0 || v > 16) return 1; c->ks_want[1] = v; }
-  else if (key == "ksplit_qkv") { if (v < 0 || v > 16) return 1; c->ks_want[2] = v; }
-  else if (key == "ksplit_fc2") { if (v < 0 || v > 16) return 1; c->ks_want[3] = v; }
-  else if (key == "xattn_nontemporal") c->xattn_nt = on ? 1 : 0;   // per context (kernel template choice)
-  else if (key == "xattn_pipeline") c->xattn_pipe = on ? 1 : 0;
-  else if (key == "xkv_fp8") {
-    if (on && !c->lowp) return 1;   // 16-bit engines only
-    if (on && !c->xkv8) {
-      const size_t n = (size_t)c->cfg.dec_layers * c->xkv_layer_elems;
-      if (dalloc(c, &c->xkv8, n, false) != 0 || dalloc(c, &c->xkv8_scale, (size_t)c->cfg.dec_layers * 2 * c->maxB * c->H * sizeof(float)) != 0)
-        return 1;
-    }
-    c->xkv_fp8 = on; c->xkv8_valid = false;   // the e4m3 copy is (re)built by the next encode
-  }
-  else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
-  else return 1;
-  g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt;
-  drop_graphs(c);
-  return 0;
-}
-
-int reset_search(ttasr_ctx* c, int B) {
-  hipStream_t s = c->stream;
-  HIPCHK(c, hipMemsetAsync(c->st.step, 0, 16, s));
-  HIPCHK(c, hipMemsetAsync(c->st.n_sampled, 0, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.last_tok, 0xff, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.pen_tok, 0xff, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.last_ts, 0xff, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.done, 0, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.n_done, 0, 16, s));
-  HIPCHK(c, hipMemsetAsync(c->st.sum_logprob, 0, B * 4, s));
-  HIPCHK(c, hipMemsetAsync(c->st.no_speech, 0, B * 4, s));
-  return 0;
-}
-
-}  // namespace
-
+// libttasr: the C ABI declared in include/ttasr.h.  One context = one GPU = one HIP stream; no hidden CPU fallback: every compute
+// entry point launches the HIP kernels of this directory or fails with an error code.  The context, the schedules and the search
+// loops live in engine_ctx.hpp / engine_alloc.hip / engine_sched.hip / engine_search.hip.
+#include "engine_ctx.hpp"
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -1083,41 +128,7 @@ void ttasr_destroy(ttasr_ctx* c) {
   delete c;
 }
 
-// Shared by the host and device entry points: `src` is a DEVICE pointer to the tensor in its source layout (float32 or
-// bf16 bits); everything from here on - conv tap re-ordering, q pre-scaling, bf16 cast, MFMA-fragment packing - runs on
-// the device.
-static int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int src_type, const int64_t* dims, int32_t ndim) {
-  if (std::string(name) == "proj_out.weight") return TTASR_OK;  // tied to embed_tokens
-  auto it = c->slots.find(name);
-  if (it == c->slots.end()) return fail(c, TTASR_E_WEIGHTS, "unknown tensor '%s'", name);
-  Slot& s = it->second;
-  int64_t n = 1;
-  for (int i = 0; i < ndim; ++i) n *= dims[i];
-  if (n != s.rows * s.cols) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': %lld elements, expected %lld", name, (long long)n,
-                                        (long long)(s.rows * s.cols));
-  int64_t conv_in = 0;
-  if (s.kind == 2) {  // [out][in][3] -> [out][3][in]: tap-major rows so conv == GEMM over a sliding window
-    if (ndim != 3 || dims[2] != 3) return fail(c, TTASR_E_WEIGHTS, "tensor '%s': expected [out][in][3]", name);
-    conv_in = dims[1];
-  }
-  const bool to_f32 = s.kind == 1 || s.kind == 3 || !c->lowp;
-  if (!to_f32 && (size_t)n > c->stage_elems) return fail(c, TTASR_E_WEIGHTS, "tensor '%s' larger than staging", name);
-  float* f32_dst = to_f32 ? (float*)s.dst : c->stage_f32;
-  launch_prep_weight(src, src_type, f32_dst, n, conv_in, s.scale, c->stream);
-  if (!to_f32) {
-    if (c->f16) {
-      launch_cast<f16_t>(c->stage_f32, (f16_t*)s.dst, n, c->stream);
-      if (s.sh_base) launch_shuffle_cast<f16_t>(c->stage_f32, (f16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
-    } else {
-      launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
-      if (s.sh_base) launch_shuffle_cast<bf16_t>(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
-    }
-  }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffers are reused by the next tensor
-  HIPCHK(c, hipGetLastError());
-  s.loaded = true;
-  return TTASR_OK;
-}
+
 
 int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
   return guarded(c, [&]() -> int {
@@ -1257,7 +268,7 @@ int ttasr_encode(ttasr_ctx* c, int32_t B, float* out_enc) {
   return guarded(c, [&]() -> int {
   TRY(check_ready(c, B));
   if (c->B_mel < B) return fail(c, TTASR_E_INVALID, "mel for %d clips requested but only %d resident", B, c->B_mel);
-  TT_DISPATCH(c, run_encoder<T>(c, B));
+  sched_encoder(c, B);
   if (out_enc) {
     const int64_t n = (int64_t)B * c->T * c->d;
     if (c->lowp) { TT_DISPATCH(c, launch_uncast<T>((const T*)c->enc_out, c->x, n, c->stream));
@@ -1301,7 +312,7 @@ int ttasr_set_encoder_output(ttasr_ctx* c, const float* enc, int32_t B) {
   c->cur = c->stream;
   c->enc_ev_class.clear();   // in-situ timing marks belong to ONE pass: start a fresh list (they used to pile up here)
   enc_mark(c, -1);
-  TT_DISPATCH(c, run_cross_kv<T>(c, B));
+  sched_cross_kv(c, B);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
   c->B_enc = B;
@@ -1358,90 +369,7 @@ int ttasr_decode_step(ttasr_ctx* c, const int32_t* tokens, int32_t B, float* log
 int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
                    const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns);
 
-namespace {
-// shared by ttasr_generate and ttasr_generate_sample: R rows, row r uses prompt (r / rows_per_clip)
-int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt, const int32_t* prompt_len, int max_prompt,
-                  const ttasr_gen_opts* o, float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp,
-                  float* out_ns) {
-  int min_plen = 1 << 30, max_plen = 0;
-  const int A = R / rows_per_clip;
-  for (int a = 0; a < A; ++a) {
-    if (prompt_len[a] < 1 || prompt_len[a] > max_prompt) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", a, prompt_len[a]);
-    if (prompt_len[a] >= c->cfg.n_text_ctx)
-      return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d leaves no room in the %d-token context", a, prompt_len[a], c->cfg.n_text_ctx);
-    min_plen = std::min(min_plen, prompt_len[a]); max_plen = std::max(max_plen, prompt_len[a]);
-    for (int j = 0; j < prompt_len[a]; ++j)
-      if (prompt[a * max_prompt + j] < 0 || prompt[a * max_prompt + j] >= c->V)
-        return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
-  }
-  RuleParams old = c->rp;
-  TRY(upload_rules(c, o, max_prompt));
-  c->rp.temperature = temperature; c->rp.seed = seed;
-  TRY(commit_rules(c, old));
-  TRY(reset_search(c, R));
-  hipStream_t s = c->stream;
-  std::vector<int32_t> pr((size_t)R * max_prompt, 0), pl(R);
-  for (int r = 0; r < R; ++r) {
-    const int a = r / rows_per_clip;
-    pl[r] = prompt_len[a];
-    memcpy(&pr[(size_t)r * max_prompt], &prompt[(size_t)a * max_prompt], (size_t)max_prompt * 4);
-  }
-  HIPCHK(c, hipMemcpyAsync(c->prompt_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpyAsync(c->plen_dev, pl.data(), R * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
-  HIPCHK(c, hipStreamSynchronize(s));  // pr / pl are stack temporaries
-  c->st.prompt = c->prompt_dev; c->st.prompt_len = c->plen_dev;
-  c->B_dec = R;
-  c->kv_div = rows_per_clip;
-  struct Restore { ttasr_ctx* c; ~Restore() { c->kv_div = 1; } } restore{c};
-  const int interval = std::max(1, o->check_interval);
-  // exclusive; prompt + sampled tokens never exceed n_text_ctx (the reference's max_length = 448: the token sampled
-  // from position n_text_ctx - 2 is the last one, position n_text_ctx - 1 is never fed)
-  const int last_step = std::min(c->cfg.n_text_ctx - 1, max_plen - 1 + o->max_new_tokens);
-  hipEventRecord(c->ev[5], s);
-  // A prefill pass runs the encoder-side GEMM kernels on rows x positions; for a handful of positions that costs more
-  // than the decode steps it replaces (measured at large-v3, 3 positions x 32 rows: +5 ms), so the
-  // <|startoftranscript|> position is only folded into the prefill when the prompt is long (previous-text prompts)
-  const int pre = prefill_positions(c, min_plen, o, /*ns_from_prefill=*/min_plen - 1 >= c->prefill_ns_min);
-  if (pre > 0) {  // positions 0..pre-1 of every row in one batched pass; the step loop resumes at position `pre`
-    TT_DISPATCH(c, run_prefill<T>(c, R, pre, rows_per_clip, max_prompt));
-    if (o->no_speech >= 0 && o->sot_index < pre) {  // the <|startoftranscript|> position was prefilled: its logits come from here
-      TT_DISPATCH(c, TRY(prefill_no_speech<T>(c, R, pre, o->sot_index, o->no_speech)));
-    }
-    c->pinned_i32[1] = pre;
-    HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev + pre, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
-  }
-  for (int step = pre; step < last_step; ++step) {
-    const bool all_forced = step + 1 < min_plen;
-    const bool need_logits = !all_forced || (o->no_speech >= 0 && step == o->sot_index);
-    // runs of sampled steps up to (and including) the next host poll replay as ONE multi-step graph of 8 or 4 steps
-    int run = 1;
-    if (c->multi_step && need_logits && step + 1 >= min_plen) {
-      int until_poll = last_step - step;                       // steps left
-      if (!o->suppress_eot) until_poll = std::min(until_poll, interval - (step + 1 - min_plen) % interval);
-      run = until_poll >= 8 ? 8 : (until_poll >= 4 ? 4 : 1);
-    }
-    TRY(step_graph(c, R, need_logits ? 0 : 2, run));
-    step += run - 1;
-    if (!o->suppress_eot && step + 1 >= min_plen && ((step + 1 - min_plen) % interval == interval - 1)) {
-      HIPCHK(c, hipMemcpyAsync(c->pinned_i32, c->st.n_done, 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(c, hipStreamSynchronize(s));
-      if (c->pinned_i32[0] >= R) break;
-    }
-  }
-  hipEventRecord(c->ev[6], s);
-  HIPCHK(c, hipMemcpyAsync(out_tokens, c->st.out_tokens, (size_t)R * c->rp.max_new * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipMemcpyAsync(out_len, c->st.n_sampled, R * 4, hipMemcpyDeviceToHost, s));
-  if (out_lp) HIPCHK(c, hipMemcpyAsync(out_lp, c->st.sum_logprob, R * 4, hipMemcpyDeviceToHost, s));
-  if (out_ns) HIPCHK(c, hipMemcpyAsync(out_ns, c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  HIPCHK(c, hipGetLastError());
-  hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
-  for (int r = 0; r < R; ++r) out_len[r] = std::min(out_len[r], c->rp.max_new);
-  return TTASR_OK;
-}
-}  // namespace
+
 
 int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
                    const ttasr_gen_opts* o, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
@@ -1481,221 +409,7 @@ int ttasr_generate_sample(ttasr_ctx* c, int32_t A, int32_t best_of, const int32_
   });
 }
 
-// Beam search over A clips x `beam` rows.  Prompts may be ragged: clip a has plens[a] tokens at prompt + a * max_prompt and
-// its <|startoftranscript|> at sots[a]; the step loop is position-synchronous, so at a given position some clips are
-// still being forced through their prompt while others already search.
-static int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t max_prompt, const int32_t* plens,
-                            const int32_t* sots, const ttasr_gen_opts* o, float patience, int32_t* out_tokens, int32_t* out_len,
-                            float* out_lp, float* out_ns) {
-  if (!c) return TTASR_E_INVALID;
-  if (beam < 1 || beam > 7 || A < 1) return fail(c, TTASR_E_INVALID, "beam must be 1..7 and n_audio >= 1");
-  const int R = A * beam;
-  TRY(check_ready(c, R));
-  if (!prompt || !plens || !out_tokens || !out_len || !o) return fail(c, TTASR_E_INVALID, "NULL argument");
-  if (A > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, A);
-  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
-  int min_plen = 1 << 30, min_sot = 1 << 30;
-  for (int a = 0; a < A; ++a) {
-    if (plens[a] < 1 || plens[a] > max_prompt || plens[a] >= c->cfg.n_text_ctx) return fail(c, TTASR_E_INVALID, "prompt_len[%d]=%d", a, plens[a]);
-    const int sot = sots ? sots[a] : o->sot_index;
-    if (o->no_speech >= 0 && out_ns && (sot < 0 || sot >= plens[a])) return fail(c, TTASR_E_INVALID, "sot_index[%d]=%d outside the prompt", a, sot);
-    min_plen = std::min(min_plen, (int)plens[a]); min_sot = std::min(min_sot, sot);
-    for (int i = 0; i < plens[a]; ++i)
-      if (prompt[(size_t)a * max_prompt + i] < 0 || prompt[(size_t)a * max_prompt + i] >= c->V)
-        return fail(c, TTASR_E_INVALID, "prompt token outside vocabulary");
-  }
-  auto sot_of = [&](int a) { return sots ? sots[a] : o->sot_index; };
-  RuleParams old_rp = c->rp;
-  TRY(upload_rules(c, o, max_prompt));
-  TRY(commit_rules(c, old_rp));
-  TRY(reset_search(c, R));
-  c->st.prompt = nullptr; c->st.prompt_len = nullptr;
-  c->B_dec = R;
-  c->kv_div = beam; c->identity_pages = 0;
-  struct Restore { ttasr_ctx* c; ~Restore() { c->kv_div = 1; c->identity_pages = 1; } } restore{c};
-  hipStream_t s = c->stream;
-  const int pps = c->pages_per_seq, n_pages = c->maxB * pps, max_new = c->rp.max_new, K = beam + 1;
-  const int max_cand = std::max(1, (int)std::lround(beam * patience));
-  std::vector<int32_t> tbl((size_t)R * pps, -1), refcnt(n_pages, 0), free_pages, cur_tok(R), pairs;
-  std::vector<std::vector<int>> seqs(R);
-  std::vector<double> sums(R, 0.0);
-  std::vector<std::map<std::vector<int>, double>> finished(A);
-  std::vector<float> h_lp((size_t)R * K), h_ns(R, 0.f);
-  std::vector<int32_t> h_id((size_t)R * K), h_state((size_t)4 * R);
-  auto rebuild_free = [&](int upto_idx) {
-    std::fill(refcnt.begin(), refcnt.end(), 0);
-    for (int r = 0; r < R; ++r)
-      for (int j = 0; j <= upto_idx && j < pps; ++j)
-        if (tbl[(size_t)r * pps + j] >= 0) refcnt[tbl[(size_t)r * pps + j]]++;
-    free_pages.clear();
-    for (int p = n_pages - 1; p >= 0; --p) if (refcnt[p] == 0) free_pages.push_back(p);
-  };
-  rebuild_free(-1);
-  for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(size_t)(r / beam) * max_prompt];
-  std::vector<char> done(A, 0);
-  std::vector<float> ns_final(A, 0.f);
-  hipEventRecord(c->ev[5], s);
-  // Batched prompt prefill: the beam rows of a clip share one prompt, so its positions are computed ONCE per clip
-  // into pages that all `beam` page tables then reference (the copy-on-write below splits the last, partially
-  // filled page on the first private write).
-  // every clip must still be inside its prompt (and before its <|startoftranscript|> when no-speech is wanted)
-  ttasr_gen_opts o_pre = *o; o_pre.sot_index = min_sot;
-  const int pre = prefill_positions(c, min_plen, &o_pre);
-  if (pre > 0) {
-    const int n_pg = (pre + 15) / 16;
-    std::vector<int32_t> ptab((size_t)A * pps, 0);
-    for (int a = 0; a < A; ++a)
-      for (int q = 0; q < n_pg; ++q) {
-        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
-        const int32_t pg = free_pages.back(); free_pages.pop_back();
-        for (int b = 0; b < beam; ++b) tbl[(size_t)(a * beam + b) * pps + q] = pg;
-        ptab[(size_t)a * pps + q] = pg;
-      }
-    HIPCHK(c, hipMemcpyAsync(c->page_table, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->prompt_dev, prompt, (size_t)A * max_prompt * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipStreamSynchronize(s));  // ptab is a stack temporary
-    TT_DISPATCH(c, run_prefill<T>(c, A, pre, 1, max_prompt));
-    c->pinned_i32[1] = pre;
-    HIPCHK(c, hipMemcpyAsync(c->st.step, &c->pinned_i32[1], 4, hipMemcpyHostToDevice, s));
-    rebuild_free(n_pg - 1);
-    for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(size_t)(r / beam) * max_prompt + pre];
-  }
-  bool stop = false;
-  for (int pos = pre; pos < c->cfg.n_text_ctx - 1 && !stop; ++pos) {
-    // 1. the page this step writes must exist and be private to the row (copy-on-write after a re-index)
-    const int j = pos / 16;
-    pairs.clear();
-    for (int r = 0; r < R; ++r) {
-      int32_t& pg = tbl[(size_t)r * pps + j];
-      if (pos % 16 == 0 || pg < 0) {
-        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
-        pg = free_pages.back(); free_pages.pop_back(); refcnt[pg] = 1;
-      } else if (refcnt[pg] > 1) {
-        if (free_pages.empty()) return fail(c, TTASR_E_NOMEM, "KV page pool exhausted");
-        const int32_t np = free_pages.back(); free_pages.pop_back();
-        pairs.push_back(pg); pairs.push_back(np);
-        refcnt[pg]--; refcnt[np] = 1; pg = np;
-      }
-    }
-    if (!pairs.empty()) {
-      HIPCHK(c, hipMemcpyAsync(c->pairs_dev, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
-      TT_DISPATCH(c, launch_copy_pages<T>((T*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s));
-    }
-    {  // page tables are stored [row][pps] with unused entries clamped to a valid page id
-      std::vector<int32_t> up(tbl);
-      for (auto& v : up) if (v < 0) v = 0;
-      HIPCHK(c, hipMemcpyAsync(c->page_table, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
-      HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, cur_tok.data(), R * 4, hipMemcpyHostToDevice, s));
-      HIPCHK(c, hipStreamSynchronize(s));  // `up` is a stack temporary
-    }
-    // 2. one decoder step over the R rows (logits only; the search itself runs on the host)
-    TRY(step_graph(c, R, 1));
-    // per clip: still forced through its prompt, searching, or finished
-    auto forced_next = [&](int a) { return prompt[(size_t)a * max_prompt + pos + 1]; };
-    bool any_sampling = false, any_ns = false;
-    for (int a = 0; a < A; ++a) {
-      any_sampling |= !done[a] && pos + 1 >= plens[a];
-      any_ns |= o->no_speech >= 0 && out_ns && pos == sot_of(a);
-    }
-    if (!any_sampling && !any_ns) {
-      for (int r = 0; r < R; ++r) cur_tok[r] = done[r / beam] ? o->eot : forced_next(r / beam);
-      continue;
-    }
-    for (int r = 0; r < R; ++r) {
-      int last = -1, pen = -1, lts = -1;
-      for (int t : seqs[r]) { pen = last; last = t; if (t >= o->timestamp_begin) lts = t; }
-      h_state[r] = (int)seqs[r].size(); h_state[R + r] = last; h_state[2 * R + r] = pen; h_state[3 * R + r] = lts;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->row_state, h_state.data(), (size_t)4 * R * 4, hipMemcpyHostToDevice, s));
-    BeamRowState bs{c->row_state, c->row_state + R, c->row_state + 2 * R, c->row_state + 3 * R, c->mask_dev};
-    launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, any_ns ? c->st.no_speech : nullptr, s);
-    HIPCHK(c, hipMemcpyAsync(h_lp.data(), c->topk_lp, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(h_id.data(), c->topk_id, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
-    if (any_ns) HIPCHK(c, hipMemcpyAsync(h_ns.data(), c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    for (int a = 0; a < A; ++a)
-      if (o->no_speech >= 0 && out_ns && pos == sot_of(a)) ns_final[a] = h_ns[a * beam];
-    if (!any_sampling) {
-      for (int r = 0; r < R; ++r) cur_tok[r] = done[r / beam] ? o->eot : forced_next(r / beam);
-      continue;
-    }
-    // 3. candidate selection per clip (Whisper BeamSearchDecoder semantics; identical sequences collapse)
-    std::vector<std::vector<int>> nseq; std::vector<double> nsum; std::vector<int> src;
-    for (int a = 0; a < A; ++a) {
-      if (done[a] || pos + 1 < plens[a]) {  // not searching at this position: hypotheses and page lists carry over unchanged
-        for (int b = 0; b < beam; ++b) { nseq.push_back(seqs[a * beam + b]); nsum.push_back(sums[a * beam + b]); src.push_back(a * beam + b); }
-        continue;
-      }
-      std::map<std::vector<int>, std::pair<double, int>> cand;
-      for (int b = 0; b < beam; ++b) {
-        const int r = a * beam + b;
-        for (int q = 0; q < K; ++q) {
-          const int tok = h_id[(size_t)r * K + q];
-          if (tok < 0) continue;
-          std::vector<int> key(seqs[r]); key.push_back(tok);
-          const double val = sums[r] + (double)h_lp[(size_t)r * K + q];
-          auto it = cand.find(key);
-          if (it == cand.end() || val > it->second.first) cand[key] = {val, r};
-        }
-      }
-      std::vector<std::pair<double, const std::vector<int>*>> order;
-      for (auto& kv : cand) order.push_back({kv.second.first, &kv.first});
-      std::sort(order.begin(), order.end(), [](auto& x, auto& y) { return x.first != y.first ? x.first > y.first : *x.second < *y.second; });
-      int saved = 0;
-      std::vector<std::pair<double, const std::vector<int>*>> fin_new;
-      for (auto& e : order) {
-        if (e.second->back() == o->eot) { fin_new.push_back(e); continue; }
-        nseq.push_back(*e.second); nsum.push_back(e.first); src.push_back(cand[*e.second].second);
-        if (++saved == beam) break;
-      }
-      for (auto& e : fin_new) { if ((int)finished[a].size() >= max_cand) break; finished[a][*e.second] = e.first; }
-      if (saved == 0) return fail(c, TTASR_E_INVALID, "beam search: no live candidate (every token masked)");
-      while (saved < beam) { nseq.push_back(nseq.back()); nsum.push_back(-1e30); src.push_back(src.back()); ++saved; }
-    }
-    // 4. re-index: hypotheses inherit their parent's page list (shared pages; refcounts rebuilt)
-    std::vector<int32_t> ntbl((size_t)R * pps, -1);
-    for (int r = 0; r < R; ++r)
-      for (int q = 0; q <= j; ++q) ntbl[(size_t)r * pps + q] = tbl[(size_t)src[r] * pps + q];
-    tbl.swap(ntbl);
-    rebuild_free(j);
-    seqs.swap(nseq); sums.swap(nsum);
-    bool all_done = true;
-    for (int a = 0; a < A; ++a) {
-      const bool searching = !done[a] && pos + 1 >= plens[a];
-      if (searching && ((int)finished[a].size() >= max_cand || (int)seqs[a * beam].size() >= max_new)) done[a] = 1;
-      for (int b = 0; b < beam; ++b) {
-        const int r = a * beam + b;
-        cur_tok[r] = done[a] ? o->eot : (searching ? seqs[r].back() : forced_next(a));
-      }
-      all_done &= (bool)done[a];
-    }
-    if (all_done) stop = true;
-  }
-  hipEventRecord(c->ev[6], s);
-  HIPCHK(c, hipStreamSynchronize(s));
-  HIPCHK(c, hipGetLastError());
-  hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
-  for (int a = 0; a < A; ++a) {
-    std::map<std::vector<int>, double> pool(finished[a]);
-    if ((int)pool.size() < beam) {
-      std::vector<int> idx(beam);
-      for (int b = 0; b < beam; ++b) idx[b] = b;
-      std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return sums[a * beam + x] > sums[a * beam + y]; });
-      for (int b : idx) { if ((int)pool.size() >= beam) break; pool.insert({seqs[a * beam + b], sums[a * beam + b]}); }
-    }
-    const std::vector<int>* best = nullptr; double best_v = -1e300, best_sum = 0;
-    for (auto& kv : pool) {
-      const double v = kv.second / std::max<size_t>(kv.first.size(), 1);
-      if (!best || v > best_v) { best = &kv.first; best_v = v; best_sum = kv.second; }
-    }
-    int n = 0;
-    for (int t : *best) if (t != o->eot && n < max_new) out_tokens[(size_t)a * max_new + n++] = t;
-    out_len[a] = n;
-    if (out_lp) out_lp[a] = (float)best_sum;
-    if (out_ns) out_ns[a] = ns_final[a];
-  }
-  return TTASR_OK;
-}
+
 
 int ttasr_generate_beam(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t plen, const ttasr_gen_opts* o,
                         float patience, int32_t* out_tokens, int32_t* out_len, float* out_lp, float* out_ns) {
@@ -1803,7 +517,7 @@ int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok
   HIPCHK(c, hipStreamSynchronize(s));  // sel is a stack temporary
   c->B_dec = 0;  // the pass reuses sequence 0's self-attention pages: any step-level decode state is gone
   AlignOut al{clip, sel_dev, probs};
-  TT_DISPATCH(c, run_prefill<T>(c, 1, n_tok, 1, n_tok, &al));
+  sched_prefill(c, 1, n_tok, 1, n_tok, &al);
   if (out_logprob) {
     // raw log p(tokens[i + 1] | tokens[0..i]): final LayerNorm + vocabulary projection, max_batch rows at a time
     for (int r0 = 0; r0 < n_tok - 1; r0 += c->maxB) {
@@ -1812,7 +526,7 @@ int ttasr_align(ttasr_ctx* c, int32_t clip, const int32_t* tokens, int32_t n_tok
       TT_DISPATCH(c, {
         launch_layernorm<T>(c->x + (size_t)r0 * c->d, c->dlnf_g, c->dlnf_b, (T*)c->dh, n, c->d, s);
         GemmArgs g = lin_args<T>(c->dh, c->emb, n, c->V, c->d); g.epi.out_f32 = c->logits; g.epi.ldc = c->ldv;
-        dec_gemm<T>(c, g, c->emb_sh);
+        sched_dec_gemm(c, g, c->emb_sh);
       });
       launch_token_logprob(c->logits, c->ldv, c->V, c->prompt_dev + r0 + 1, lp_dev + r0, n, s);
     }
@@ -1917,26 +631,26 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
     } else if (k == "enc_gemm_fc1") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].w1; g.M = B * c->T; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->enc[0].b1; g.epi.act = 1; g.epi.out_t = c->mid;
-      TT_DISPATCH(c, gemm<T>(c, g));
+      sched_gemm(c, g);
       bytes = ((double)B * T_ * (d + ffn) + ffn * d) * e; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_gemm_qkv") {
       GemmArgs g; g.A = c->h; g.W = c->enc[0].wqkv; g.M = B * c->T; g.N = 3 * c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = 3 * c->d; g.epi.bias = c->enc[0].bqkv; g.epi.out_t = c->qkv;
-      TT_DISPATCH(c, gemm<T>(c, g));
+      sched_gemm(c, g);
       bytes = ((double)B * T_ * 4 * d + 3 * d * d) * e; flops = 2.0 * B * T_ * d * 3 * d;
     } else if (k == "enc_gemm_out") {
       GemmArgs g; g.A = c->att; g.W = c->enc[0].wo; g.M = B * c->T; g.N = c->d; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->d; g.epi.bias = c->enc[0].bo;
       const bool delta = c->lowp && !c->force_basic && !c->enc_res_epilogue;  // the epilogue run_encoder uses
       if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
-      TT_DISPATCH(c, gemm<T>(c, g));
+      sched_gemm(c, g);
       bytes = ((double)B * T_ * d + d * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * d;
     } else if (k == "enc_gemm_fc2") {
       GemmArgs g; g.A = c->mid; g.W = c->enc[0].w2; g.M = B * c->T; g.N = c->d; g.K = c->ffn; g.lda = c->ffn; g.ldw = c->ffn;
       g.epi.ldc = c->d; g.epi.bias = c->enc[0].b2;
       const bool delta = c->lowp && !c->force_basic && !c->enc_res_epilogue;
       if (delta) g.epi.out_t = c->h; else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
-      TT_DISPATCH(c, gemm<T>(c, g));
+      sched_gemm(c, g);
       bytes = ((double)B * T_ * ffn + ffn * d) * e + (delta ? e : 8.0) * B * T_ * d; flops = 2.0 * B * T_ * d * ffn;
     } else if (k == "enc_attn") {
       TT_DISPATCH(c, {
@@ -1950,12 +664,12 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
     } else if (k == "dec_gemm_fc1") {
       GemmArgs g; g.A = c->dh; g.W = c->dec[0].w1; g.M = B; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->dec[0].b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      TT_DISPATCH(c, dec_gemm<T>(c, g, c->lowp ? c->dec[0].w1_sh : nullptr));
+      TT_DISPATCH(c, sched_dec_gemm(c, g, c->lowp ? c->dec[0].w1_sh : nullptr));
       bytes = (ffn * d + (double)B * (d + ffn)) * e; flops = 2.0 * B * d * ffn;
     } else if (k == "logits_gemm") {
       GemmArgs g; g.A = c->dh; g.W = c->emb; g.M = B; g.N = c->V; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ldv; g.epi.out_f32 = c->logits;
-      TT_DISPATCH(c, dec_gemm<T>(c, g, c->lowp ? c->emb_sh : nullptr));
+      TT_DISPATCH(c, sched_dec_gemm(c, g, c->lowp ? c->emb_sh : nullptr));
       bytes = (double)c->V * d * e + (double)B * c->V * 4.0; flops = 2.0 * B * d * c->V;
     } else {
       return fail(c, TTASR_E_INVALID, "unknown kernel '%s'", name);

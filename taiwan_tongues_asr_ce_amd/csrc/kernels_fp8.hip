@@ -231,8 +231,8 @@ bool launch_cross_attn_fp8(const T* q, const uint8_t* K8, const uint8_t* V8, con
   else {
     if (sq.n > 4 || Tk < 1) return false;
     const size_t lds = sizeof(float) * (Tk + 4 * 64 + 2 * 4);
-    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_fp8_kernel<T, true, 3>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
-    else hipLaunchKernelGGL((cross_attn_fp8_kernel<T, false, 3>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_fp8_kernel<T, true, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
+    else hipLaunchKernelGGL((cross_attn_fp8_kernel<T, false, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
     return true;
   }
 }

@@ -337,8 +337,8 @@ def test_adapter_returns_none_for_a_vad_emptied_chunk_and_retries_only_on_opt_in
 
 
 def test_every_set_option_key_is_documented_in_the_header():
-    """include/ttasr.h lists the ttasr_set_option keys; the list must be exactly what the library accepts (engine.hip)."""
-    src = open(os.path.join(ROOT, "taiwan_tongues_asr_ce_amd", "csrc", "engine.hip")).read()
+    """include/ttasr.h lists the ttasr_set_option keys; the list must be exactly what the library accepts (engine_search.hip)."""
+    src = open(os.path.join(ROOT, "taiwan_tongues_asr_ce_amd", "csrc", "engine_search.hip")).read()
     body = src[src.index("int set_option(ttasr_ctx* c, const std::string& key, int v) {"):]
     body = body[:body.index("\n}\n")]
     accepted = set(re.findall(r'key == "([a-z_0-9]+)"', body))

@@ -200,25 +200,48 @@ def test_f16_device_intake_and_facade():
 def test_f16_full_depth_b32_tokens_equal_the_f32_parity_engine():
     """Full whisper-large-v3 geometry (32 + 32 layers), 32 different clips: the fp16 engine's greedy tokens against the f32
     PARITY engine's (itself within 1e-3 of the oracle at this depth: tests/test_gpu_full_size.py).  Measured on the benchmark
-    workload: all 32 x 128 tokens identical (same CRC-32, profiles/bench_r3_f16.json vs bench_r3_f32_parity_mode.json).  Gate: at
-    least 30 of the 32 rows identical over 24 tokens (a random-weight near-tie may flip a row), scores within 0.02 per token."""
+    workload: all 32 x 128 tokens identical (same CRC-32; bench.py output_check.vs_f32_parity_tokens).  Gate on these other clips:
+    a row may leave the f32 engine's sequence ONLY at a near-tie of the f32 engine's own logits - at the first divergent position
+    the f32 logit of its choice exceeds the f32 logit of the fp16 engine's choice by less than 0.04 (2 x the fp16 logit tolerance;
+    teacher-forced through the f32 step API) - at least 26 of the 32 rows are identical over 24 tokens (measured 29-32: which
+    near-ties flip moves with the compiler's fma contraction of the fp16 epilogues), scores of identical rows within 0.02 per token."""
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_F32
     from taiwan_tongues_asr_ce_amd.engine import Engine
     dims = PRESETS["large-v3"]
     B, n_new = 32, 24
     clips = [synth.noise_clip(700 + i) if i % 3 else synth.tonal_clip(700 + i) for i in range(B)]
     outs = {}
+    e32 = None
     for compute in (COMPUTE_F16, COMPUTE_F32):
         e = Engine(dims, compute, B)
         e.load_weights(synth.iter_weights(dims))
         st = e.special
         e.log_mel(clips, want_output=False)
         e.encode(B)
-        outs[compute] = e.generate([[st.sot, st.lang_zh, st.transcribe, st.no_timestamps]] * B, e.gen_opts(n_new, False, suppress_eot=True))
-        e.close()
+        prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+        outs[compute] = e.generate([prompt] * B, e.gen_opts(n_new, False, suppress_eot=True))
+        if compute == COMPUTE_F32:
+            e32 = e                      # kept: the step API grades the divergences below
+        else:
+            e.close()
     a, b = outs[COMPUTE_F16], outs[COMPUTE_F32]
     same = [x == y for x, y in zip(a.tokens, b.tokens)]
-    assert sum(same) >= 30, sum(same)
+    first = [next((j for j, (p, q) in enumerate(zip(x, y)) if p != q), n_new) for x, y in zip(a.tokens, b.tokens)]
+    assert sum(same) >= 26, (sum(same), first)
+    last = max([j for j in first if j < n_new], default=-1)
+    if last >= 0:                        # teacher-force the f32 engine on its own tokens up to the last divergence
+        e32.decode_reset(B)
+        lg = None
+        for t in prompt:
+            lg = e32.decode_step([t] * B)
+        for j in range(last + 1):
+            for r in range(B):
+                if first[r] == j:
+                    gap = float(lg[r, b.tokens[r][j]] - lg[r, a.tokens[r][j]])
+                    assert 0.0 <= gap < 0.04, (r, j, gap)
+            if j < last:
+                lg = e32.decode_step([b.tokens[r][j] for r in range(B)])
+    e32.close()
     for r in range(B):
         if same[r]:
             assert abs(float(a.sum_logprob[r]) - float(b.sum_logprob[r])) < 0.02 * n_new, r
