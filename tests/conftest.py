@@ -22,6 +22,22 @@ def golden_dir():
 
 
 @pytest.fixture(scope="session", autouse=True)
+def _oracle_thread_count():
+    """The CPU oracle (torch) is the host-time cost of the GPU suite.  On the GPU box (256 logical CPUs) torch defaults to 128
+    threads, and its many small ops run ~3x SLOWER that way than with 32 (measured round 4: oracle encoder over 16 clips at
+    large-v3 width 12.9 s -> 4.7 s, an 8-token greedy decode 4-6 s -> 1-1.7 s; bench.py's cpu_baseline caps at 32 for the same
+    reason).  VERDICT round 3, next #6."""
+    try:
+        import torch
+        n = os.cpu_count() or 1
+        if n > 32:
+            torch.set_num_threads(32)
+    except Exception:
+        pass
+    yield
+
+
+@pytest.fixture(scope="session", autouse=True)
 def _synthetic_weight_cache():
     """The GPU suite builds the same seeded synthetic tensors many times (whisper-large-v3 alone - 1.5 B values, ~10 s of Philox
     per generation on the GPU box's host - for eight engines / oracle copies): memoise synth.make_tensor for the session.  Cached

@@ -118,7 +118,8 @@ def test_f16_measured_shape_b32_token_equality_under_margin():
     kinds = (synth.noise_clip, synth.tonal_clip, synth.noise_clip, synth.burst_clip)
     B = 32
     clips = [kinds[i % 4](100 + i) for i in range(B)]
-    mel_ref = np.stack([R.log_mel(c, pd.n_mels) for c in clips])
+    rows = list(range(0, 8)) + list(range(24, 32))     # the oracle recomputes 16 of the 32 rows (both 16-row halves; host time)
+    mel_ref = np.stack([R.log_mel(clips[r], pd.n_mels) for r in rows])
     enc_ref = encode_chunked(mel_ref, Wh, rd)
     from taiwan_tongues_asr_ce_amd.engine import Engine
     e = Engine(pd, COMPUTE_F16, B)
@@ -126,21 +127,21 @@ def test_f16_measured_shape_b32_token_equality_under_margin():
     st = e.special
     e.log_mel(clips, want_output=False)
     enc = e.encode(B, want_output=True)
-    err = np.abs(enc - enc_ref.numpy())
+    err = np.abs(enc[rows] - enc_ref.numpy())
     assert err.max() < 0.04 and err.mean() < 0.003, (float(err.max()), float(err.mean()))
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
     xkv = R.cross_kv(enc_ref, Wh, rd)
     cache = R.SelfCache.empty(rd.dec_layers)
     e.decode_reset(B)
     for t in prompt + [1234]:
-        lg = e.decode_step([t] * B)
-        want = R.decoder_forward(torch.full((B, 1), t), cache, xkv, Wh, rd)[:, 0].numpy()
+        lg = e.decode_step([t] * B)[rows]
+        want = R.decoder_forward(torch.full((len(rows), 1), t), cache, xkv, Wh, rd)[:, 0].numpy()
         assert np.abs(lg - want).max() < 0.02, (t, float(np.abs(lg - want).max()))
     opts = e.gen_opts(8, False, check_interval=1)
     res = e.generate([prompt] * B, opts)
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
                     suppress=[opts.suppress[i] for i in range(opts.n_suppress)], begin_suppress=[220, st.eot], timestamps=False)
-    g = teacher_forced(res.tokens, prompt, enc_ref, Wh, rd, rules, tol=0.04, margin=0.04)
+    g = teacher_forced([res.tokens[r] for r in rows], prompt, enc_ref, Wh, rd, rules, tol=0.04, margin=0.04)
     assert g.n_clear >= 0.6 * g.n_steps, g
     again = e.generate([prompt] * B, opts)
     assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)

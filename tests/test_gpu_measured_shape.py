@@ -6,7 +6,8 @@ decides nothing else, but a batch of 16 / 32 UNSHARED rows at 20 heads is also w
 (`self_attn_decode_kernel<..., IDENT>`) and the 32-row fragment-packed decode GEMMs (`gemm_skinny_kernel<4, 1, ...>`, K =
 1280 / 5120) run with a full batch.  So: whisper-large-v3 WIDTH (d 1280, 20 heads, ffn 5120, 128 mels, vocab 51 866), 2 + 2
 layers (the oracle stays affordable), B = 16 and B = 32 different clips, against oracle/whisper_ref.py -
-  f32 engine : encoder 1e-3, logits of every prompt position 1e-3 (north-star tolerance), greedy tokens identical, every row;
+  f32 engine : encoder 1e-3, logits of every prompt position 1e-3 (north-star tolerance), greedy tokens identical, on the 16 rows
+               (first and last eight of the batch) the oracle recomputes - the engine always runs all 16 / 32 rows;
   bf16 engine: logits within 0.08 of the oracle holding the bf16-rounded weights; teacher-forced, every choice within 0.15 of
                the oracle's best and EQUAL to the oracle's token wherever its top-2 margin exceeds 0.16 (2 x the tolerance);
                at least 60 % of the steps carry such a margin (the test is not vacuous).
@@ -27,6 +28,13 @@ torch.set_grad_enabled(False)
 DIMS = PRESETS["large-v3-w2"]
 BMAX = 32
 N_NEW = 8
+# The engine always runs the full batch; the CPU oracle recomputes 16 of the 32 rows - the first and the last eight, so both
+# 32-row halves of every kernel's row mapping are graded (round 4: the GPU suite's host time)
+ORACLE_ROWS = list(range(0, 8)) + list(range(24, 32))
+
+
+def _rows(B):
+    return [r for r in ORACLE_ROWS if r < B]
 
 
 def _clips(n):
@@ -39,7 +47,7 @@ def world():
     """32 different clips, their oracle log-mel, and the f32 / bf16-rounded weights (one generation for the module)."""
     sd = synth.state_dict(DIMS)
     clips = _clips(BMAX)
-    mel_ref = np.stack([R.log_mel(c, DIMS.n_mels) for c in clips])
+    mel_ref = {r: R.log_mel(clips[r], DIMS.n_mels) for r in ORACLE_ROWS}
     return sd, clips, mel_ref
 
 
@@ -60,31 +68,33 @@ def test_f32_single_pass_kernels_meet_the_north_star_tolerance(world):
     sd, clips, mel_ref = world
     rd = R.Dims(**DIMS.as_dict())
     W = R.to_torch(sd)
-    enc_ref = encode_chunked(mel_ref, W, rd)
+    enc_all = encode_chunked(np.stack([mel_ref[r] for r in ORACLE_ROWS]), W, rd)      # rows ORACLE_ROWS, in that order
     e = _engine(COMPUTE_F32, sd)
     st = e.special
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
     for B in (16, 32):                                      # B x 20 heads = 320 / 640 (row, head) items: single-pass kernels
+        rows = _rows(B)
+        enc_ref = enc_all[:len(rows)]
         mel = e.log_mel(clips[:B])
-        np.testing.assert_allclose(mel, mel_ref[:B], atol=2e-4)
+        np.testing.assert_allclose(mel[rows], np.stack([mel_ref[r] for r in rows]), atol=2e-4)
         enc = e.encode(B, want_output=True)
-        np.testing.assert_allclose(enc, enc_ref[:B].numpy(), atol=1e-3, rtol=0)
-        xkv = R.cross_kv(enc_ref[:B], W, rd)
+        np.testing.assert_allclose(enc[rows], enc_ref.numpy(), atol=1e-3, rtol=0)
+        xkv = R.cross_kv(enc_ref, W, rd)
         cache = R.SelfCache.empty(rd.dec_layers)
         e.decode_reset(B)
         for t in prompt + [1234, 777]:                      # the prompt positions and two text positions (self-KV of 5-6 keys)
-            lg = e.decode_step([t] * B)
-            want = R.decoder_forward(torch.full((B, 1), t), cache, xkv, W, rd)[:, 0].numpy()
+            lg = e.decode_step([t] * B)[rows]
+            want = R.decoder_forward(torch.full((len(rows), 1), t), cache, xkv, W, rd)[:, 0].numpy()
             err = np.abs(lg - want).max(axis=1)
             assert err.max() < 1e-3, (B, t, int(err.argmax()), float(err.max()))
         for ts in (False, True):
             p = prompt[:3] if ts else prompt
             opts = e.gen_opts(N_NEW, ts, check_interval=1)
             res = e.generate([p] * B, opts)
-            ref = R.greedy_decode(enc_ref[:B], p, W, rd, _rules(e, opts, ts), N_NEW, no_speech_token=st.no_speech)
-            assert res.tokens == ref.tokens, (B, ts)
-            np.testing.assert_allclose(res.no_speech_prob, ref.no_speech_prob, rtol=2e-3, atol=1e-6)
-            np.testing.assert_allclose(res.sum_logprob, ref.sum_logprob, atol=2e-3 * N_NEW)
+            ref = R.greedy_decode(enc_ref, p, W, rd, _rules(e, opts, ts), N_NEW, no_speech_token=st.no_speech)
+            assert [res.tokens[r] for r in rows] == ref.tokens, (B, ts)
+            np.testing.assert_allclose(res.no_speech_prob[rows], ref.no_speech_prob, rtol=2e-3, atol=1e-6)
+            np.testing.assert_allclose(res.sum_logprob[rows], ref.sum_logprob, atol=2e-3 * N_NEW)
     e.close()
 
 
@@ -92,29 +102,31 @@ def test_bf16_single_pass_kernels_token_equality_under_margin(world):
     sd, clips, mel_ref = world
     rd = R.Dims(**DIMS.as_dict())
     Wb = R.to_torch(sd, round_bf16=True)
-    enc_ref = encode_chunked(mel_ref, Wb, rd)
+    enc_all = encode_chunked(np.stack([mel_ref[r] for r in ORACLE_ROWS]), Wb, rd)
     e = _engine(COMPUTE_BF16, sd)
     st = e.special
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
     for B in (16, 32):
+        rows = _rows(B)
+        enc_ref = enc_all[:len(rows)]
         e.log_mel(clips[:B], want_output=False)
         enc = e.encode(B, want_output=True)
-        err = np.abs(enc - enc_ref[:B].numpy())
+        err = np.abs(enc[rows] - enc_ref.numpy())
         assert err.max() < 0.15 and err.mean() < 0.012, (B, float(err.max()), float(err.mean()))
-        xkv = R.cross_kv(enc_ref[:B], Wb, rd)
+        xkv = R.cross_kv(enc_ref, Wb, rd)
         cache = R.SelfCache.empty(rd.dec_layers)
         e.decode_reset(B)
         for t in prompt + [1234, 777]:
-            lg = e.decode_step([t] * B)
-            want = R.decoder_forward(torch.full((B, 1), t), cache, xkv, Wb, rd)[:, 0].numpy()
+            lg = e.decode_step([t] * B)[rows]
+            want = R.decoder_forward(torch.full((len(rows), 1), t), cache, xkv, Wb, rd)[:, 0].numpy()
             err = np.abs(lg - want).max(axis=1)
             assert err.max() < 0.08, (B, t, int(err.argmax()), float(err.max()))
         for ts in (False, True):
             p = prompt[:3] if ts else prompt
             opts = e.gen_opts(N_NEW, ts, check_interval=1)
             res = e.generate([p] * B, opts)                 # the graph path: K-split slabs, ticketed select
-            g = teacher_forced(res.tokens, p, enc_ref[:B], Wb, rd, _rules(e, opts, ts), tol=0.15, margin=0.16)
-            assert g.n_steps >= B * 2 and g.n_clear >= 0.6 * g.n_steps, (B, ts, g)
+            g = teacher_forced([res.tokens[r] for r in rows], p, enc_ref, Wb, rd, _rules(e, opts, ts), tol=0.15, margin=0.16)
+            assert g.n_steps >= len(rows) * 2 and g.n_clear >= 0.6 * g.n_steps, (B, ts, g)
             # the same rows through a replay are bit-identical (no float atomics anywhere)
             again = e.generate([p] * B, opts)
             assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
