@@ -118,7 +118,7 @@ def test_f16_measured_shape_b32_token_equality_under_margin():
     kinds = (synth.noise_clip, synth.tonal_clip, synth.noise_clip, synth.burst_clip)
     B = 32
     clips = [kinds[i % 4](100 + i) for i in range(B)]
-    rows = list(range(0, 8)) + list(range(24, 32))     # the oracle recomputes 16 of the 32 rows (both 16-row halves; host time)
+    rows = list(range(B))     # rows the oracle recomputes (all of them; a subset here bounds host time if ever needed)
     mel_ref = np.stack([R.log_mel(clips[r], pd.n_mels) for r in rows])
     enc_ref = encode_chunked(mel_ref, Wh, rd)
     from taiwan_tongues_asr_ce_amd.engine import Engine

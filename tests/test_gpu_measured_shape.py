@@ -6,8 +6,7 @@ decides nothing else, but a batch of 16 / 32 UNSHARED rows at 20 heads is also w
 (`self_attn_decode_kernel<..., IDENT>`) and the 32-row fragment-packed decode GEMMs (`gemm_skinny_kernel<4, 1, ...>`, K =
 1280 / 5120) run with a full batch.  So: whisper-large-v3 WIDTH (d 1280, 20 heads, ffn 5120, 128 mels, vocab 51 866), 2 + 2
 layers (the oracle stays affordable), B = 16 and B = 32 different clips, against oracle/whisper_ref.py -
-  f32 engine : encoder 1e-3, logits of every prompt position 1e-3 (north-star tolerance), greedy tokens identical, on the 16 rows
-               (first and last eight of the batch) the oracle recomputes - the engine always runs all 16 / 32 rows;
+  f32 engine : encoder 1e-3, logits of every prompt position 1e-3 (north-star tolerance), greedy tokens identical, every row;
   bf16 engine: logits within 0.08 of the oracle holding the bf16-rounded weights; teacher-forced, every choice within 0.15 of
                the oracle's best and EQUAL to the oracle's token wherever its top-2 margin exceeds 0.16 (2 x the tolerance);
                at least 60 % of the steps carry such a margin (the test is not vacuous).
@@ -28,9 +27,9 @@ torch.set_grad_enabled(False)
 DIMS = PRESETS["large-v3-w2"]
 BMAX = 32
 N_NEW = 8
-# The engine always runs the full batch; the CPU oracle recomputes 16 of the 32 rows - the first and the last eight, so both
-# 32-row halves of every kernel's row mapping are graded (round 4: the GPU suite's host time)
-ORACLE_ROWS = list(range(0, 8)) + list(range(24, 32))
+# The engine always runs the full batch; ORACLE_ROWS are the rows the CPU oracle recomputes (a subset keeps host time down when
+# needed; since the oracle runs on 32 torch threads - conftest.py - it is every row again)
+ORACLE_ROWS = list(range(32))   # all rows (the 32-thread oracle of conftest.py makes that affordable: 14 -> ~22 s per test)
 
 
 def _rows(B):
