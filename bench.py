@@ -189,10 +189,11 @@ def pmc_busy_from_profile(kernels: dict, sigs, flops):
     return round(sum(flops) / sum(f / b for f, b in zip(flops, fr)), 4), None
 
 
-def _self_launch(n: int) -> int:
+def _self_launch(n: int, cmd=None) -> int:
     """`python bench.py --gpus N` from a bare shell (no torchrun environment): this parent process touches no GPU - it
     only spawns the N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set exactly as
-    torch.distributed.run would) and relays rank 0's JSON line.  Nothing is exec'ed over an initialised GPU process."""
+    torch.distributed.run would) and relays rank 0's JSON line.  Nothing is exec'ed over an initialised GPU process.
+    `cmd` (tests): the rank command line instead of this script's own."""
     import socket
     import subprocess
     import torch
@@ -205,7 +206,7 @@ def _self_launch(n: int) -> int:
         # fewer devices than ranks: the ranks share GPUs and talk over gloo (RCCL refuses two ranks per device).
         # Plumbing check only - the line then says so in config.parallelism
         env["TTASR_DIST_BACKEND"] = "gloo"
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+    procs = [subprocess.Popen(cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
     # rank 0's stdout is drained on a thread so that the parent can watch every child: when ANY rank dies, the others - which

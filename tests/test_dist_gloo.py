@@ -241,3 +241,34 @@ def test_missing_master_port_fails_fast_for_a_real_group(monkeypatch):
     monkeypatch.delenv("MASTER_PORT", raising=False)
     with pytest.raises(RuntimeError, match="MASTER_PORT"):
         D.init_process_group("gloo")
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies(tmp_path, capsys):
+    """`python bench.py --gpus N` (its own launcher) must not leave ranks parked in a collective when a
+    peer dies - it ends them by PID and returns non-zero with a one-line reason; a clean run relays rank 0's JSON line."""
+    import importlib.util
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r = int(os.environ['RANK']); mode = sys.argv[1]\n"
+        "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_PORT'] and os.environ['LOCAL_RANK'] == str(r)\n"
+        "if mode == 'die' and r == 1:\n"
+        "    time.sleep(0.5); sys.exit(7)\n"
+        "if mode == 'die':\n"
+        "    time.sleep(120)          # a rank waiting in a collective for the dead peer\n"
+        "if r == 0:\n"
+        "    print('library chatter'); print('{\"value\": 1}')\n")
+    t0 = time.time()
+    rc = bench._self_launch(3, cmd=[sys.executable, str(script), "die"])
+    assert rc == 7 and time.time() - t0 < 60          # not the 120 s the survivors would have slept
+    err = capsys.readouterr().err
+    assert "rank 1 exited with code 7" in err
+    rc = bench._self_launch(3, cmd=[sys.executable, str(script), "ok"])
+    out = capsys.readouterr().out
+    assert rc == 0 and out.strip() == '{"value": 1}'
