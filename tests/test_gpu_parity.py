@@ -425,3 +425,55 @@ def test_set_option_variants_stay_within_tolerance_and_bad_keys_are_refused(tiny
         assert e.lib.ttasr_set_option(e.h, key.encode(), val) == -1
         assert b"option" in e.lib.ttasr_last_error(e.h)
     e.close()
+
+
+def test_round4_options_are_bit_identical_to_their_off_form():
+    """The three round-4 defaults must not change a single bit of the output (that is why the benchmark's token CRC survived the
+    round): runs of 8 / 4 greedy steps replayed as one graph (`multi_step_graph`) - with natural EOT stopping and host polls every
+    1 / 3 / 4 / 8 / 20 steps, so that runs start and end on every alignment -, the software-pipelined cross-attention
+    (`xattn_pipeline`; large-v3 width, 16 unshared rows: the single-pass kernel's case) and the persistent encoder GEMM
+    (`enc_gemm_persistent`; enough tiles for a workgroup to walk two)."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    # (a) multi-step graphs, tiny model, natural stopping
+    e = _engine("tiny", COMPUTE_BF16, 4)
+    st = e.special
+    clips = [synth.noise_clip(40 + i) for i in range(4)]
+    e.log_mel(clips, want_output=False)
+    e.encode(4)
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    for interval in (1, 3, 4, 8, 20):
+        outs = []
+        for on in (1, 0):
+            e.set_option("multi_step_graph", on)
+            for n_new, sup in ((37, False), (16, True)):
+                r = e.generate([prompt] * 4, e.gen_opts(n_new, False, suppress_eot=sup, check_interval=interval))
+                outs.append((on, r.tokens, r.sum_logprob.copy(), r.no_speech_prob.copy()))
+        half = len(outs) // 2
+        for a, b in zip(outs[:half], outs[half:]):
+            assert a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), interval
+    e.set_option("multi_step_graph", 1)
+    e.close()
+    # (b) pipelined cross-attention + persistent GEMM at large-v3 width (2 + 2 layers), 16 different clips
+    dims = PRESETS["large-v3-w2"]
+    e = Engine(dims, COMPUTE_BF16, 16)
+    e.load_weights(synth.iter_weights(dims))
+    st = e.special
+    clips = [synth.noise_clip(60 + i) if i % 2 else synth.tonal_clip(60 + i) for i in range(16)]
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    ref = None
+    for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0}):
+        for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, **key_vals}.items():
+            e.set_option(k, v)
+        e.log_mel(clips, want_output=False)
+        enc = e.encode(16, want_output=True)
+        e.decode_reset(16)
+        lg = [e.decode_step([t] * 16).copy() for t in prompt]
+        r = e.generate([prompt] * 16, e.gen_opts(12, False, suppress_eot=True))
+        cur = (enc, lg, r.tokens, r.sum_logprob.copy())
+        if ref is None:
+            ref = cur
+        else:
+            assert np.array_equal(cur[0], ref[0]), key_vals
+            assert all(np.array_equal(x, y) for x, y in zip(cur[1], ref[1])), key_vals
+            assert cur[2] == ref[2] and np.array_equal(cur[3], ref[3]), key_vals
+    e.close()
