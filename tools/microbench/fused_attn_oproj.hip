@@ -51,10 +51,13 @@ template <typename T> __device__ __forceinline__ fu32x4 pack8(const float (&v)[8
 }  // namespace
 
 // NB10 = n-blocks per wave (d / 32 / G rounded up, <= 10 at d = 1280, G = 4)
-template <typename T, int G, bool IDENT, int NBW>
+// OPROJ = false (round-4 side experiment): only the one-wave-per-(row, head) attention - no workgroup barrier at all - writing the
+// head outputs as T rows to att_out like self_attn_decode_kernel; the out-projection stays the K-split GEMM launch.
+template <typename T, int G, bool IDENT, int NBW, bool OPROJ = true>
 __global__ __launch_bounds__(G * 64) void self_attn_oproj_kernel(T* pool_, const int32_t* page_table_, int pages_per_seq_, int row0_,
                                                                  const int32_t* step_, int H_, int B_, SlabIn sq, const T* qkv_,
-                                                                 const bf16_t* Wo_sh_, float* oslab_, int64_t oslab_stride_) {
+                                                                 const bf16_t* Wo_sh_, float* oslab_, int64_t oslab_stride_,
+                                                                 T* att_out_ = nullptr) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int UNROLL = G <= 4 ? 8 : 4;   // 8 keys per wave-instruction x UNROLL cached keys per round trip (registers: 2 waves per SIMD at G = 8)
   __shared__ __attribute__((aligned(16))) uint16_t o16[G][64];
@@ -71,12 +74,14 @@ __global__ __launch_bounds__(G * 64) void self_attn_oproj_kernel(T* pool_, const
   // ---- this wave's share of the head's Wo slice: n-blocks wave, wave + G, ...; 4 k-steps each.  Requested FIRST: nothing
   // they depend on is produced by the preceding launch
   fu32x4 wv[NBW][4];
+  if constexpr (OPROJ) {
 #pragma unroll
-  for (int i = 0; i < NBW; ++i) {
-    const int nb = min(wave + G * i, n_blocks - 1);
-    const fu32x4* wp = (const fu32x4*)Wo_sh + ((int64_t)nb * ks_per + 4 * h) * 64 + lane;
+    for (int i = 0; i < NBW; ++i) {
+      const int nb = min(wave + G * i, n_blocks - 1);
+      const fu32x4* wp = (const fu32x4*)Wo_sh + ((int64_t)nb * ks_per + 4 * h) * 64 + lane;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wv[i][kk] = wp[kk * 64];
+      for (int kk = 0; kk < 4; ++kk) wv[i][kk] = wp[kk * 64];
+    }
   }
   const int pos = *step;
   const int bg = b + row0;
@@ -162,6 +167,11 @@ __global__ __launch_bounds__(G * 64) void self_attn_oproj_kernel(T* pool_, const
   float o[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = stride_reduce<8>(acc[j] * wgt, OpSum{}) * inv;
+  if constexpr (!OPROJ) {
+    T* att_out = sgpr_pin_ptr(att_out_);
+    if (rin == 0 && row_ok) *(fu32x4*)(att_out + (int64_t)b * d + h * 64 + sub * 8) = pack8<T>(o);
+    return;
+  }
   if (rin == 0) *(fu32x4*)&o16[wave][sub * 8] = pack8<T>(o);
   __syncthreads();
   // ---- out-projection of this head: A = head outputs (m = row of the group), B = Wo fragments (k x n)
@@ -215,6 +225,20 @@ bool launch_self_attn_oproj(T* kv_pool, const int32_t* page_table, int pages_per
     return true;
   }
 }
+// attention only, one wave per (row, head), 4 rows per workgroup (no workgroup barrier); T rows out
+template <typename T>
+void launch_self_attn_wave(T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off, int identity_pages, int row0,
+                           const int32_t* step, int B, int H, SlabIn sqkv, const T* qkv, T* att, hipStream_t s) {
+  T* pool = kv_pool + pool_layer_off;
+  if (identity_pages)
+    hipLaunchKernelGGL((self_attn_oproj_kernel<T, 4, true, 1, false>), dim3(H, (B + 3) / 4), dim3(256), 0, s, pool, page_table, pages_per_seq, row0,
+                       step, H, B, sqkv, qkv, (const bf16_t*)nullptr, (float*)nullptr, (int64_t)0, att);
+  else
+    hipLaunchKernelGGL((self_attn_oproj_kernel<T, 4, false, 1, false>), dim3(H, (B + 3) / 4), dim3(256), 0, s, pool, page_table, pages_per_seq, row0,
+                       step, H, B, sqkv, qkv, (const bf16_t*)nullptr, (float*)nullptr, (int64_t)0, att);
+}
+template void launch_self_attn_wave<bf16_t>(bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*, int, int, SlabIn, const bf16_t*, bf16_t*, hipStream_t);
+
 template bool launch_self_attn_oproj<bf16_t>(bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*, int, int, SlabIn, const bf16_t*,
                                              const bf16_t*, float*, int64_t, int, hipStream_t);
 template bool launch_self_attn_oproj<f16_t>(f16_t*, const int32_t*, int, int64_t, int, int, const int32_t*, int, int, SlabIn, const f16_t*,

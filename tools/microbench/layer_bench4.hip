@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
   }
   const int pps = 28; bf16_t* pool = (bf16_t*)dmal((size_t)B * pps * 2 * H * 16 * 64 * 2, 1);
   int32_t* pt = (int32_t*)dmal(B * pps * 4, 0); int32_t* step = (int32_t*)dmal(16, 0);
-  { int v = 64; hipMemcpy(step, &v, 4, hipMemcpyHostToDevice); }
+  { int v = argc > 3 ? atoi(argv[3]) : 64; hipMemcpy(step, &v, 4, hipMemcpyHostToDevice); printf("position %d\n", v); }
   float* x_ln2 = (float*)dmal(B * d * 4, 0);   // check only: the residual rows right after LN2's sum (before the cross-attention)
   bool snap = false;
   auto run_layer = [&](int l, int variant, int& pend, int64_t& pend_stride) {
@@ -89,7 +89,11 @@ int main(int argc, char** argv) {
     const bool fuse_q = variant == 1 || variant == 4, fuse_o = variant == 2 || variant == 3 || variant == 4;
     ln();
     SlabIn sqkv = split(wqkv[l], h, 3 * d, d, 2, bias);
-    if (fuse_o) {
+    if (variant == 5) {   // one wave per (row, head) self-attention (no workgroup barriers), standard out-proj GEMM
+      launch_self_attn_wave<bf16_t>(pool, pt, pps, 0, 1, 0, step, B, H, sqkv, qkv, att, s);
+      pend = split(wo[l], att, d, d, 4, bias).n; pend_stride = (int64_t)B * d;
+      ln();
+    } else if (fuse_o) {
       // the qkv slabs occupy slab[0 .. 2*B*3d); the per-head out-proj slabs go behind them
       float* oslab = slab + (size_t)2 * B * 3 * d;
       launch_self_attn_oproj<bf16_t>(pool, pt, pps, 0, 1, 0, step, B, H, sqkv, qkv, wo[l], oslab, (int64_t)B * d, variant == 3 ? 8 : 4, s);
@@ -132,7 +136,7 @@ int main(int argc, char** argv) {
   std::vector<float> xr2((size_t)B * d);
   run_check(0, xr, ar);
   hipMemcpy(xr2.data(), x_ln2, xr2.size() * 4, hipMemcpyDeviceToHost);
-  for (int v : {1, 2, 3, 4}) {
+  for (int v : {1, 2, 3, 4, 5}) {
     run_check(v, xt, at_);
     if (v != 1) { xr = xr2; at_ = ar; }   // compare after LN2 (the cross-attention output is only compared for variant 1)
     double ex = 0, ea = 0, mx = 0, ma = 0;
@@ -142,10 +146,10 @@ int main(int argc, char** argv) {
            (ex > 0.02 * mx + 1e-3 || ea > 0.02 * ma + 1e-4) ? "   <-- MISMATCH" : "");
   }
   // ---- timing: interleaved rounds in one process
-  const char* names[5] = {"shipped 11-launch plan", "q projection inside cross-attention", "self-attn + out-proj G=4 (per-head slabs)",
-                          "self-attn + out-proj G=8", "both (variants 1 + 2)"};
-  hipGraphExec_t ex[5];
-  for (int v = 0; v < 5; ++v) {
+  const char* names[6] = {"shipped 11-launch plan", "q projection inside cross-attention", "self-attn + out-proj G=4 (per-head slabs)",
+                          "self-attn + out-proj G=8", "both (variants 1 + 2)", "self-attn as one wave per (row, head), 11 launches"};
+  hipGraphExec_t ex[6];
+  for (int v = 0; v < 6; ++v) {
     hipGraph_t gr;
     hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     int pend = 0; int64_t ps = 0;
@@ -153,7 +157,7 @@ int main(int argc, char** argv) {
     hipStreamEndCapture(s, &gr); hipGraphInstantiate(&ex[v], gr, nullptr, nullptr, 0); hipGraphDestroy(gr);
   }
   for (int round = 0; round < 3; ++round)
-    for (int v = 0; v < 5; ++v) {
+    for (int v = 0; v < 6; ++v) {
       if (only >= 0 && v != only && v != 0) continue;
       double us = timeit(s, [&] { hipGraphLaunch(ex[v], s); }, reps) / L;
       printf("round %d variant %d (%s): %.2f us per layer\n", round, v, names[v], us);
