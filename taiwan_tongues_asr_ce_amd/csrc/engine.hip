@@ -697,9 +697,11 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
 }
 
 int ttasr_bench_kernel_signature(ttasr_ctx* c, char* buf, int32_t len) {
+  return guarded(c, [&]() -> int {   // not re-entrant like every other call: bench_sig belongs to the last ttasr_bench_kernel
   if (!c || !buf || len < 1) return TTASR_E_INVALID;
   snprintf(buf, (size_t)len, "%s", c->bench_sig.c_str());
   return TTASR_OK;
+  });
 }
 
 }  // extern "C"
