@@ -78,6 +78,18 @@ def test_fp8_cross_kv_tracks_the_bf16_engine_and_the_oracle():
         e8.set_option("xkv_fp8", 0)                          # back to the 16-bit cache: identical to the bf16 engine again
         back = e8.generate([prompt] * B, opts)
         assert back.tokens == base.tokens and np.array_equal(back.sum_logprob, base.sum_logprob)
+    # the opt-in short window (streaming utterances: 150 encoder positions) - the e4m3 copy follows the window's frame count
+    short = [synth.noise_clip(300 + i, 48000) for i in range(16)]
+    e8.set_option("xkv_fp8", 1)
+    for e in (e16, e8):
+        e.set_audio_ctx(150)
+        e.log_mel(short, want_output=False)
+        e.encode(16)
+        e.decode_reset(16)
+    worst = 0.0
+    for t in prompt + [1234, 777]:
+        worst = max(worst, float(np.abs(e16.decode_step([t] * 16) - e8.decode_step([t] * 16)).max()))
+    assert 0.0 < worst < 0.12, worst
     e16.close(); e8.close()
 
 

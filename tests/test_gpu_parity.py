@@ -460,20 +460,24 @@ def test_round4_options_are_bit_identical_to_their_off_form():
     st = e.special
     clips = [synth.noise_clip(60 + i) if i % 2 else synth.tonal_clip(60 + i) for i in range(16)]
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
-    ref = None
-    for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0}):
-        for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, **key_vals}.items():
-            e.set_option(k, v)
-        e.log_mel(clips, want_output=False)
-        enc = e.encode(16, want_output=True)
-        e.decode_reset(16)
-        lg = [e.decode_step([t] * 16).copy() for t in prompt]
-        r = e.generate([prompt] * 16, e.gen_opts(12, False, suppress_eot=True))
-        cur = (enc, lg, r.tokens, r.sum_logprob.copy())
-        if ref is None:
-            ref = cur
-        else:
-            assert np.array_equal(cur[0], ref[0]), key_vals
-            assert all(np.array_equal(x, y) for x, y in zip(cur[1], ref[1])), key_vals
-            assert cur[2] == ref[2] and np.array_equal(cur[3], ref[3]), key_vals
+    short = [synth.noise_clip(90 + i, 48000) for i in range(16)]
+    for n_ctx, cl in ((0, clips), (150, short), (46, short)):     # Whisper's window; the streaming path's 3-s window; a ragged one
+        e.set_audio_ctx(n_ctx)                                    # (46 frames: the last batch of the pipelined stream is partial)
+        ref = None
+        for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0}):
+            for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, **key_vals}.items():
+                e.set_option(k, v)
+            e.log_mel(cl, want_output=False)
+            enc = e.encode(16, want_output=True)
+            e.decode_reset(16)
+            lg = [e.decode_step([t] * 16).copy() for t in prompt]
+            r = e.generate([prompt] * 16, e.gen_opts(12, False, suppress_eot=True))
+            cur = (enc, lg, r.tokens, r.sum_logprob.copy())
+            if ref is None:
+                ref = cur
+            else:
+                assert np.array_equal(cur[0], ref[0]), (n_ctx, key_vals)
+                assert all(np.array_equal(x, y) for x, y in zip(cur[1], ref[1])), (n_ctx, key_vals)
+                assert cur[2] == ref[2] and np.array_equal(cur[3], ref[3]), (n_ctx, key_vals)
+    e.set_audio_ctx(0)
     e.close()
