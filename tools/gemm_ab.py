@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--variants", default="3,4")
+    ap.add_argument("--no-insitu", action="store_true")
     args = ap.parse_args()
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
@@ -56,7 +57,7 @@ def main():
                 tot_f += r["flops"]; tot_t += r["ms"]
             row["flop_weighted_tflops"] = round(tot_f / tot_t / 1e9, 1)
             print(json.dumps(row), flush=True)
-    for v in variants:     # in situ: one real encoder pass with an event after every launch
+    for v in ([] if args.no_insitu else variants):     # in situ: one real encoder pass with an event after every launch
         e.set_option("enc_gemm", v)
         e.set_option("enc_kernel_timing", 1)
         e.encode(B); e.encode(B)
