@@ -481,3 +481,45 @@ def test_round4_options_are_bit_identical_to_their_off_form():
                 assert cur[2] == ref[2] and np.array_equal(cur[3], ref[3]), (n_ctx, key_vals)
     e.set_audio_ctx(0)
     e.close()
+
+
+def test_kernel_options_are_per_context_and_the_graph_cache_is_bounded():
+    """ADVICE round 3: `xattn_nontemporal` / `weights_nontemporal` used to be process-wide globals - an option set on one context
+    changed what another context's thread launched.  Now every C-ABI call copies its own context's options into the launchers'
+    thread-locals: context A with the pipelined cross-attention switched off launches `cross_attn_decode_kernel`, context B
+    (untouched, used after A's call) still launches `cross_attn_pipe_kernel` (ttasr_bench_kernel_signature).  And the captured
+    decode-step graphs live in an LRU cache of 16: twenty different batch sizes evict the oldest, which are then re-captured with
+    identical results (VERDICT round 3, next #8)."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    dims = PRESETS["large-v3-w2"]
+    sd = synth.state_dict(dims)
+    a, b = Engine(dims, COMPUTE_BF16, 16), Engine(dims, COMPUTE_BF16, 16)
+    clips = [synth.noise_clip(70 + i) for i in range(16)]
+    for e in (a, b):
+        e.load_weights(sd.items())
+        e.log_mel(clips, want_output=False)
+        e.encode(16)
+    a.set_option("xattn_pipeline", 0)
+    a.set_option("xattn_nontemporal", 0)
+    sig_b = b.bench_kernel("xattn", 16, iters=1)["signature"]           # B runs AFTER A changed its own options
+    sig_a = a.bench_kernel("xattn", 16, iters=1)["signature"]
+    assert sig_b.startswith("cross_attn_pipe_kernel<unsigned short, true,"), sig_b
+    assert sig_a.startswith("cross_attn_decode_kernel<unsigned short, false, 4, 8, false,"), sig_a
+    assert b.bench_kernel("xattn", 16, iters=1)["signature"] == sig_b   # ... and again after A launched
+    a.close(); b.close()
+    # graph cache: 20 batch sizes x the greedy step graphs (1-step and multi-step) on one context
+    e = _engine("tiny", COMPUTE_BF16, 20)
+    st = e.special
+    clips = [synth.noise_clip(80 + i) for i in range(20)]
+    e.log_mel(clips, want_output=False)
+    e.encode(20)
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    first = {}
+    for B in list(range(1, 21)) + [1, 2, 3, 20]:                        # the tail revisits evicted entries
+        r = e.generate([prompt] * B, e.gen_opts(10, False, suppress_eot=True, check_interval=4))
+        key = B
+        if key in first:
+            assert r.tokens == first[key][0] and np.array_equal(r.sum_logprob, first[key][1]), B
+        else:
+            first[key] = (r.tokens, r.sum_logprob.copy())
+    e.close()
