@@ -133,7 +133,7 @@ struct ttasr_ctx {
   // decode-step graphs keyed by (B, with_logits)
   struct GraphKey { int B; int mode; int variant; hipGraphExec_t exec; };
   std::vector<GraphKey> graphs;   // least recently used first
-  static constexpr size_t kMaxGraphs = 16;
+  static constexpr size_t kMaxGraphs = 32;   // per batch size up to four step graphs exist (1- / 4- / 8-step greedy, logits-only): 8 batch sizes stay resident
   RuleParams rp{};
 };
 
