@@ -301,9 +301,14 @@ class Rules:
     suppress_eot: bool = False         # benchmark mode: never stop
 
 
-def apply_rules(logits: torch.Tensor, sampled: Sequence[int], rules: Rules) -> torch.Tensor:
+def apply_rules(logits: torch.Tensor, sampled: Sequence[int], rules: Rules, ts_prob_rule: Optional[bool] = None,
+                ts_prob_margin: Optional[List[float]] = None) -> torch.Tensor:
     """One row f32[V] + the tokens sampled so far for that row (after the prompt) -> processed row.
-    [HF-LP]:1816 (begin suppress), :1869 (suppress), :2000-2047 (timestamp rules)."""
+    [HF-LP]:1816 (begin suppress), :1869 (suppress), :2000-2047 (timestamp rules).
+    Test-side hooks for the one DISCONTINUOUS rule ("timestamp probability mass > best text probability => text is masked",
+    [HF-LP]:2040-2047): `ts_prob_margin`, when a list, receives logsumexp(timestamp log-probs) - max(text log-prob) (the rule
+    fires when > 0); `ts_prob_rule` = True / False forces the rule on / off instead of evaluating it (graders use it to grade a
+    16-bit engine's token when that margin is inside the logit tolerance).  Defaults = the reference behaviour."""
     s = logits.clone().float()
     n = len(sampled)
     if n == 0 and len(rules.begin_suppress):
@@ -331,7 +336,10 @@ def apply_rules(logits: torch.Tensor, sampled: Sequence[int], rules: Rules) -> t
             if rules.max_initial_timestamp_index is not None:
                 s[tb + rules.max_initial_timestamp_index + 1:] = NEG_INF
         lp = torch.log_softmax(s, dim=-1)
-        if torch.logsumexp(lp[tb:], dim=-1) > lp[:tb].max():
+        m = torch.logsumexp(lp[tb:], dim=-1) - lp[:tb].max()
+        if ts_prob_margin is not None:
+            ts_prob_margin.append(float(m))
+        if (m > 0) if ts_prob_rule is None else ts_prob_rule:
             s[:tb] = NEG_INF
     return s
 

@@ -199,7 +199,7 @@ void launch_layernorm_add(float* x, const T* delta, const float* gamma, const fl
 struct LnPre {
   const float* bias = nullptr;   // [d]
   const float* slab = nullptr;   // [n_slab][slab_stride] f32 partial tiles of the preceding K-split residual GEMM
-  int n_slab = 0;                // <= 20
+  int n_slab = 0;                // <= 16 (the decode slabs of the context hold 16 K slices)
   int64_t slab_stride = 0;
   float* x_out = nullptr;        // [rows][d] updated residual rows (may alias x)
   const int32_t* tok = nullptr;  // [rows]
@@ -238,7 +238,8 @@ bool launch_gemm_skinny(const T16* Wsh, const T16* x, int B, int N, int K, const
 int gemm_skinny_ksplit(int B, int N, int K, int want);
 // vocabulary projection: persistent workgroups that keep the activation rows in registers (kernels_skinny.hip); false: shape unsupported
 template <typename T16> bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s, int device);
-void gemm_vocab_init(int device);   // once per device, outside any stream capture (ttasr_create)
+void gemm_vocab_init(int device);   // once per device (std::call_once), outside any stream capture (ttasr_create)
+void gemm_tiles_init(int device);   // same for the tiled encoder GEMMs: dynamic-LDS opt-ins + CU count of the persistent grid
 // mel
 // geom_dev (optional): int64 [B][3] = {lead, reflect_end, valid_frames} per clip - window-of-a-file geometry, kernels_misc.hip
 void launch_mel(const float* pcm, int64_t pcm_stride, const int64_t* n_samples_dev, int B, int n_mels, int n_frames,
@@ -329,6 +330,11 @@ template <> inline const char* sig_type<struct f16_t>() { return "f16_t"; }
 // Kernel-variant switches of the launchers (A/B experiments).  Thread-local: every C-ABI call copies its CONTEXT's setting in
 // before it launches anything (engine.hip guarded()), so an option set on one context never changes what another context's
 // thread launches or what its captured graphs hold.
+// A launcher asked for a configuration it has no kernel for (unreachable behind ttasr_create's geometry limits and
+// ttasr_set_option's ranges; kept as a guard for future callers): it records the reason here and launches NOTHING; the C-ABI
+// call that was running returns TTASR_E_INVALID with this text (engine.hip guarded()).  A library never abort()s its host.
+extern thread_local char g_launch_fault[160];
+void launch_fault(const char* fmt, ...);
 extern thread_local int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs
 extern thread_local int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant
 // beam search: processed log-probabilities and ids of the k best tokens of every row (rules applied from the

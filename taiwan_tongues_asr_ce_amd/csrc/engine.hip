@@ -17,8 +17,12 @@ static int guarded(ttasr_ctx* c, F&& f) {
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
   if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; }   // this context's kernel variants for everything f launches
+  g_launch_fault[0] = 0;
   try {
-    return f();
+    const int rc = f();
+    // a launcher that had no kernel for what it was asked (common.hpp launch_fault) launched nothing: the call's output is invalid
+    if (g_launch_fault[0] && rc == TTASR_OK) return fail(c, TTASR_E_INVALID, "launcher refused: %s", g_launch_fault);
+    return rc;
   } catch (const std::bad_alloc&) {
     return fail(c, TTASR_E_NOMEM, "host allocation failed");
   } catch (const std::exception& e) {
@@ -69,6 +73,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
   p->cur = p->stream;
   gemm_vocab_init(device_id);
+  gemm_tiles_init(device_id);
   {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
     const size_t d = p->d, ffn = p->ffn, T = p->T, B = p->maxB;
     const size_t w = ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);
@@ -110,6 +115,7 @@ int ttasr_set_option(ttasr_ctx* c, const char* key, int32_t value) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int rc = set_option(c, key, value);
+  if (rc == 2) return TTASR_E_NOMEM;   // an allocation of the option failed: dalloc's message is the error text
   if (rc) return fail(c, TTASR_E_INVALID, "unknown option '%s' (or value %d out of range)", key, value);
   return TTASR_OK;
   });

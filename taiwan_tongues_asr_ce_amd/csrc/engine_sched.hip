@@ -399,7 +399,11 @@ int step_graph(ttasr_ctx* c, int B, int mode, int nsteps) {
     for (int i = 0; i < nsteps; ++i) TT_DISPATCH(c, run_decode_step<T>(c, B, mode));
     return 0;
   }
-  const int variant = (c->kv_div * 2 + c->identity_pages) * 64 + nsteps;
+  // everything that decides WHICH kernels a captured step holds is part of the key: whether the e4m3 cross-KV copy is live
+  // changes with encode (run_cross_kv builds it), not only with set_option (a graph captured between
+  // set_option(xkv_fp8) and the next encode held the 16-bit kernel and kept replaying after the copy existed)
+  const int fp8_live = (c->xkv_fp8 && c->xkv8_valid) ? 1 : 0;
+  const int variant = ((c->kv_div * 2 + c->identity_pages) * 2 + fp8_live) * 64 + nsteps;
   for (size_t i = 0; i < c->graphs.size(); ++i) {
     if (c->graphs[i].B == B && c->graphs[i].mode == mode && c->graphs[i].variant == variant) {
       // most recently used at the back: the cache is bounded (the streaming micro-batcher varies B from 1 to max_batch rows)

@@ -76,10 +76,10 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   else if (key == "xattn_pipeline") c->xattn_pipe = on ? 1 : 0;
   else if (key == "xkv_fp8") {
     if (on && !c->lowp) return 1;   // 16-bit engines only
-    if (on && !c->xkv8) {
+    if (on && (!c->xkv8 || !c->xkv8_scale)) {   // the small allocation first; the mode turns on only when BOTH exist
       const size_t n = (size_t)c->cfg.dec_layers * c->xkv_layer_elems;
-      if (dalloc(c, &c->xkv8, n, false) != 0 || dalloc(c, &c->xkv8_scale, (size_t)c->cfg.dec_layers * 2 * c->maxB * c->H * sizeof(float)) != 0)
-        return 1;
+      if (!c->xkv8_scale && dalloc(c, &c->xkv8_scale, (size_t)c->cfg.dec_layers * 2 * c->maxB * c->H * sizeof(float)) != 0) return 2;
+      if (!c->xkv8 && dalloc(c, &c->xkv8, n, false) != 0) return 2;   // 2: dalloc's error text (out of memory) stands
     }
     c->xkv_fp8 = on; c->xkv8_valid = false;   // the e4m3 copy is (re)built by the next encode
   }

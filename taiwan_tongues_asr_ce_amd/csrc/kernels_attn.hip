@@ -6,6 +6,7 @@
 // Replaces CTranslate2's MultiHeadAttention layer (un-vendored; arithmetic per HF modeling_whisper.py
 // :215-238, 241-356): q arrives pre-scaled by 1/8 (folded into the weights), softmax in f32.
 #include "common.hpp"
+#include <cstdarg>
 #include <cstdio>
 
 // ------------------------------------------------------------------------------------------------
@@ -154,6 +155,14 @@ template <> __device__ __forceinline__ void store_row<f16_t>(f16_t* p, const flo
 // over pos+1 keys (the new key/value are taken from registers, never re-read from memory).
 // ------------------------------------------------------------------------------------------------
 constexpr int PAGE = 16;
+thread_local char g_launch_fault[160] = "";
+void launch_fault(const char* fmt, ...) {
+  if (g_launch_fault[0]) return;   // the first fault of a call is the one reported
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_launch_fault, sizeof(g_launch_fault), fmt, ap);
+  va_end(ap);
+}
 thread_local bool g_kernel_sig_on = false;
 thread_local char g_kernel_sig[192] = "";
 thread_local int g_xattn_variant = 3;  // bit 0: option xattn_nontemporal (nontemporal K/V loads), bit 1: option xattn_pipeline (software-pipelined form); default both

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
 
 void launch_select(const float* logits, DecState st, RuleParams rp, int B, float* out_rows, hipStream_t s, int32_t* ticket,
                    int total_rows) {
-  if (rp.V > LOGIT_NIT * 4096) { fprintf(stderr, "ttasr: vocabulary %d > %d\n", rp.V, LOGIT_NIT * 4096); abort(); }
+  if (rp.V > LOGIT_NIT * 4096) { launch_fault("select: vocabulary %d > %d", rp.V, LOGIT_NIT * 4096); return; }
   const bool sample = rp.temperature > 0.f;
 #define TTASR_SELECT(S_, H_) hipLaunchKernelGGL((select_kernel<S_, H_>), dim3(B), dim3(1024), 0, s, logits, st, rp, out_rows, ticket, total_rows)
   if (out_rows) { if (sample) TTASR_SELECT(true, true); else TTASR_SELECT(false, true); }

@@ -345,16 +345,15 @@ __global__ __launch_bounds__(320) void layernorm_rows_kernel(const float* __rest
 template <typename T>
 void launch_layernorm_rows(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const LnPre& pre,
                            hipStream_t s) {
-  if (d > 1280 || (d & 3)) { fprintf(stderr, "ttasr: layernorm_rows needs d <= 1280, d %% 4 == 0 (got %d)\n", d); abort(); }
+  if (d > 1280 || (d & 3)) { launch_fault("layernorm_rows needs d <= 1280, d %% 4 == 0 (got %d)", d); return; }
+  if (pre.n_slab > 16) { launch_fault("layernorm_rows sums at most 16 slabs (got %d)", pre.n_slab); return; }
   dim3 grid(rows), block(320);  // five waves whatever d is (ttasr_create: d <= 1280): threads past d / 4 contribute zeros
   if (pre.tok) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, true>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab == 0) hipLaunchKernelGGL((layernorm_rows_kernel<T, 0, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 2) hipLaunchKernelGGL((layernorm_rows_kernel<T, 2, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 4) hipLaunchKernelGGL((layernorm_rows_kernel<T, 4, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
   else if (pre.n_slab <= 8) hipLaunchKernelGGL((layernorm_rows_kernel<T, 8, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
-  else if (pre.n_slab <= 16) hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
-  else if (pre.n_slab <= 20) hipLaunchKernelGGL((layernorm_rows_kernel<T, 20, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);  // per-head slabs (kernels_fused.hip)
-  else { fprintf(stderr, "ttasr: layernorm_rows sums at most 20 slabs (got %d)\n", pre.n_slab); abort(); }
+  else hipLaunchKernelGGL((layernorm_rows_kernel<T, 16, false>), grid, block, 0, s, x, gamma, beta, out, d, pre);
 }
 template void launch_layernorm_rows<float>(const float*, const float*, const float*, float*, int, int, const LnPre&, hipStream_t);
 template void launch_layernorm_rows<bf16_t>(const float*, const float*, const float*, bf16_t*, int, int, const LnPre&, hipStream_t);

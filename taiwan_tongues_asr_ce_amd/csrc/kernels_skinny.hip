@@ -25,6 +25,7 @@
 // self-attention kernel (q, k, v) and the cross-attention kernel (q).  fc1 (GELU needs the full sum) and the vocabulary
 // GEMM stay unsplit.
 #include "common.hpp"
+#include <mutex>
 #include <cstdlib>
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
@@ -311,7 +312,10 @@ __global__ __launch_bounds__(512) void gemm_vocab_kernel(const bf16_t* __restric
 // hipGraph stream capture, where attribute / property calls do not belong - under rocprofv3 they crashed the capture): the
 // opt-in to > 64 KiB of dynamic LDS for every instantiation and the CU count that sizes the persistent grid.
 static int g_vocab_cus[64] = {0};
-void gemm_vocab_init(int device) {
+static std::once_flag g_vocab_once[64];
+static void vocab_init_once(int device);
+void gemm_vocab_init(int device) { std::call_once(g_vocab_once[device & 63], vocab_init_once, device); }
+static void vocab_init_once(int device) {
   hipDeviceProp_t p;
   g_vocab_cus[device & 63] = hipGetDeviceProperties(&p, device) == hipSuccess ? p.multiProcessorCount : 256;
 #define TTASR_VOCAB_ATTR(T_, RB_)                                                                                                          \

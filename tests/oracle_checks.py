@@ -65,18 +65,57 @@ def teacher_forced(tokens: Sequence[Sequence[int]], prompt: Sequence[int], enc_r
     for i in range(n):
         nxt: List[int] = []
         for b in range(B):
-            s = np.asarray(R.apply_rules(logits[b], list(tokens[b][:i]), rules))
             c = int(tokens[b][i])
-            assert s[c] > -np.inf, f"row {b} step {i}: the engine chose a masked token ({c})"
-            gap = float(s.max() - s[c])
-            assert gap < tol, f"row {b} step {i}: chosen logit {gap:.4f} below the oracle's best (tolerance {tol})"
-            g.worst = max(g.worst, gap)
-            top2 = np.partition(s, -2)[-2:]
-            if top2[1] - top2[0] > margin:
-                assert int(np.argmax(s)) == c, f"row {b} step {i}: token {c} != oracle argmax {int(np.argmax(s))} at a clear margin"
-                g.n_clear += 1
-            g.n_steps += 1
+            g.add(_grade_choice(logits[b], list(tokens[b][:i]), c, rules, tol, margin, f"row {b} step {i}"))
             nxt.append(c)
         if i + 1 < n:
             logits = R.decoder_forward(torch.tensor(nxt, dtype=torch.long)[:, None], cache, xkv, W, rd)[:, 0]
+    return g
+
+
+def _grade_choice(row_logits, sampled, c, rules, tol, margin, where) -> Graded:
+    """One choice `c` of the engine against the oracle's raw logits of that position.  The timestamp-probability rule is the one
+    discontinuous processor (text is masked when the timestamp probability MASS exceeds the best text probability): when the
+    oracle's own margin of that comparison is inside `tol`, a 16-bit engine may legitimately land on the other side, so the choice
+    is graded under the rule outcome the ENGINE took (text token -> rule off, timestamp -> rule on) and the step is not counted
+    as clear."""
+    g = Graded(n_steps=1)
+    mg: list = []
+    s = np.asarray(R.apply_rules(row_logits, sampled, rules, ts_prob_margin=mg))
+    near_rule = bool(mg) and abs(mg[0]) < tol
+    if near_rule:
+        s = np.asarray(R.apply_rules(row_logits, sampled, rules, ts_prob_rule=bool(c >= rules.timestamp_begin)))
+    assert s[c] > -np.inf, f"{where}: the engine chose a masked token ({c}); timestamp-rule margin {mg[0] if mg else None}"
+    gap = float(s.max() - s[c])
+    assert gap < tol, f"{where}: chosen logit {gap:.4f} below the oracle's best (tolerance {tol})"
+    g.worst = gap
+    top2 = np.partition(s, -2)[-2:]
+    if top2[1] - top2[0] > margin and not near_rule:
+        assert int(np.argmax(s)) == c, f"{where}: token {c} != oracle argmax {int(np.argmax(s))} at a clear margin"
+        g.n_clear = 1
+    return g
+
+
+def teacher_forced_causal(tokens: Sequence[Sequence[int]], prompt: Sequence[int], enc_ref: torch.Tensor, W, rd, rules, tol: float,
+                          margin: float, rows_per_pass: int = 4) -> Graded:
+    """teacher_forced() for LONG rows: instead of one oracle step per position, ONE causal oracle pass per row over
+    prompt + tokens[:-1] gives the logits of every position at once (the `_teacher_forced_gap` pattern of
+    test_gpu_max_context.py, batched over `rows_per_pass` rows of equal length).  Same grading: every choice allowed and
+    within `tol` of the oracle's best allowed logit; equal to the oracle's argmax wherever its top-2 margin exceeds `margin`."""
+    B = len(tokens)
+    assert enc_ref.shape[0] == B
+    n = len(tokens[0])
+    assert all(len(t) == n for t in tokens), "rows of one causal pass must have one length"
+    g = Graded()
+    P = len(prompt)
+    for lo in range(0, B, rows_per_pass):
+        hi = min(B, lo + rows_per_pass)
+        xkv = R.cross_kv(enc_ref[lo:hi], W, rd)
+        seq = torch.tensor([list(prompt) + [int(t) for t in tokens[b][:-1]] for b in range(lo, hi)], dtype=torch.long)
+        logits = R.decoder_forward(seq, R.SelfCache.empty(rd.dec_layers), xkv, W, rd)
+        for b in range(lo, hi):
+            toks = [int(t) for t in tokens[b]]
+            for i, c in enumerate(toks):
+                g.add(_grade_choice(logits[b - lo, P - 1 + i], toks[:i], c, rules, tol, margin, f"row {b} step {i}"))
+        del logits
     return g

@@ -66,6 +66,10 @@ def test_fp8_cross_kv_tracks_the_bf16_engine_and_the_oracle():
         assert 0.0 < worst < 0.12, worst                     # > 0: the fp8 kernel really ran
         # (ii) greedy tokens: equal to the bf16 engine's wherever its margin is clear
         res = e8.generate([prompt] * B, opts)
+        # the fp8 kernel is live INSIDE generate()'s captured graphs too: the graphs captured above - after set_option, before the
+        # e4m3 copy existed - hold the 16-bit kernel and must not be replayed now (the graph key left the
+        # cache's liveness out and this check passed on stale bf16 graphs).  Scores are f32 sums of log-probs: any fp8 read moves them
+        assert not np.array_equal(res.sum_logprob, base.sum_logprob), "generate() replayed the 16-bit graphs: fp8 path not live"
         again = e8.generate([prompt] * B, opts)
         assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)   # bit-reproducible
         rows_equal = sum(a == b for a, b in zip(res.tokens, base.tokens))

@@ -1,8 +1,8 @@
 """GPU, BASELINE.json's full configuration (whisper-large-v3 geometry, 32+32 layers, B = 32, bf16, 128 new tokens).
 The oracle cannot run all of it in test time, so: (i) size-independent properties of the whole batch - the
 logits-processor invariants on every emitted token, finite scores, bit-identical replays, clip-order equivariance;
-(ii) four ROWS of the B = 32 batch recomputed by the CPU oracle at full depth (prompt logits within 0.08, teacher-forced
-token equality under margin), also for a clip decoded alone and by beam(1); (iii) one clip end to end in f32 (1e-3) and bf16."""
+(ii) eight ROWS of the B = 32 batch recomputed by the CPU oracle at full depth over 24 tokens (prompt logits within 0.08,
+teacher-forced token equality under margin), also for a clip decoded alone and by beam(1); (iii) one clip end to end in f32 (1e-3) and bf16."""
 import numpy as np
 import pytest
 
@@ -82,13 +82,15 @@ def oracle_full():
 
 
 def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full):
-    """The MEASURED configuration held to the oracle: whisper-large-v3 geometry, 32 + 32 layers,
-    B = 32 different clips, bf16 - i.e. the single-pass cross-attention kernel, the identity-page self-attention and the 32-row
-    decode GEMMs exactly as bench.py runs them.  Four rows of the batch (first, last, two inside) are recomputed by the CPU
-    oracle (bf16-rounded weights; ~4 s of encoder each on the box's host): the step-API logits of the four prompt positions
-    are within 0.08, and under teacher forcing each of the first 4 greedy tokens of the B = 32 generate() is within 0.15 of the
-    oracle's best allowed logit and IS the oracle's token wherever its top-2 margin exceeds 0.16.  The same rows decoded ALONE
-    (B = 1: frame-split cross-attention, other GEMM tiles) and by beam search with one hypothesis pass the same grading."""
+    """The MEASURED configuration held to the oracle (deepened in round 5 - VERDICT round 4, next #1):
+    whisper-large-v3 geometry, 32 + 32 layers, B = 32 different clips, bf16 - i.e. the single-pass cross-attention kernel, the
+    identity-page self-attention and the 32-row decode GEMMs exactly as bench.py runs them (EOT suppressed, no host poll).  EIGHT
+    rows of the batch (first, last, six inside) are recomputed by the CPU oracle (bf16-rounded weights) as one batch of 8: the
+    step-API logits of the four prompt positions are within 0.08, and under teacher forcing each of the first 24 greedy tokens of
+    the B = 32 generate() - positions 4...27: across the KV-page boundary at 16 and three replays of the 8-step graph - is within
+    0.15 of the oracle's best allowed logit and IS the oracle's token wherever its top-2 margin exceeds 0.16.  Two of the rows
+    decoded ALONE (B = 1: frame-split cross-attention, other GEMM tiles) and by beam search with one hypothesis pass the same
+    grading."""
     import torch
     from oracle import whisper_ref as R
     from oracle_checks import Graded, teacher_forced
@@ -97,22 +99,27 @@ def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full)
     st = e.special
     rd, Wb = oracle_full
     clips = [synth.noise_clip(i) if i % 3 else synth.tonal_clip(i) for i in range(B)]
-    rows = (0, 5, 17, 31)
+    rows = (0, 3, 5, 11, 17, 22, 27, 31)
+    n_graded = 24
     prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
     e.log_mel(clips, want_output=False)
     e.encode(B)
     e.decode_reset(B)
     step_logits = [e.decode_step([t] * B) for t in prompt]               # B = 32 rows through the step API (same kernels)
-    opts = e.gen_opts(8, False, check_interval=1 << 20)
+    opts = e.gen_opts(n_graded, False, suppress_eot=True, check_interval=1 << 20)
     res = e.generate([prompt] * B, opts)                                 # the benchmark's route: graph replay, K-split slabs
+    assert all(len(t) == n_graded for t in res.tokens)
     rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
-                    suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False)
+                    suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False, suppress_eot=True)
+    rules_solo = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                         suppress=default_suppress(st, rd.vocab), begin_suppress=[220, st.eot], timestamps=False)
     mel = np.stack([R.log_mel(clips[b], e.dims.n_mels) for b in rows])
     total, solo_total = Graded(), Graded()
     from oracle_checks import prompt_state
-    # the four rows go through the oracle as ONE batch of 4 (the 3.6 GB of decoder weights are read once per position instead of
-    # once per position and row; round 4: 103 s -> ~45 s of host time); row k's slice of the batched state serves its own gradings
-    enc_all = R.encoder_forward(torch.from_numpy(mel), Wb, rd)
+    # the eight rows go through the oracle as ONE batch (the 3.6 GB of decoder weights are read once per position instead of
+    # once per position and row); row k's slice of the batched state serves its own gradings
+    from oracle_checks import encode_chunked
+    enc_all = encode_chunked(mel, Wb, rd)
     start_all = prompt_state(prompt, enc_all, Wb, rd)
 
     def row_state(k):
@@ -123,8 +130,8 @@ def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full)
     for k, b in enumerate(rows):
         for t, lg, want in zip(prompt, step_logits, start_all[3]):
             assert float(np.abs(lg[b] - want[k].numpy()).max()) < 0.08, (b, t)
-    total.add(teacher_forced([res.tokens[b] for b in rows], prompt, enc_all, Wb, rd, rules, tol=0.15, margin=0.16, n_check=4,
-                             start=start_all))
+    total.add(teacher_forced([res.tokens[b] for b in rows], prompt, enc_all, Wb, rd, rules, tol=0.15, margin=0.16,
+                             n_check=n_graded, start=start_all))
     for k, b in enumerate(rows):
         if b in (5, 17):   # the same clip alone, greedy and beam(1)
             e.log_mel([clips[b]], want_output=False)
@@ -138,13 +145,13 @@ def test_full_depth_b32_rows_teacher_forced_against_the_oracle(eng, oracle_full)
                 st2 = ([tuple(torch.cat([t, t]) for t in layer) for layer in start[0]],
                        R.SelfCache([torch.cat([t, t]) for t in start[1].k], [torch.cat([t, t]) for t in start[1].v]),
                        torch.cat([start[2]] * 2), None)
-                solo_total.add(teacher_forced([solo, beam1], prompt, enc2, Wb, rd, rules, tol=0.15, margin=0.16, start=st2))
+                solo_total.add(teacher_forced([solo, beam1], prompt, enc2, Wb, rd, rules_solo, tol=0.15, margin=0.16, start=st2))
             else:
-                solo_total.add(teacher_forced([solo], prompt, enc_all[k:k + 1], Wb, rd, rules, tol=0.15, margin=0.16, start=start))
-                solo_total.add(teacher_forced([beam1], prompt, enc_all[k:k + 1], Wb, rd, rules, tol=0.15, margin=0.16, start=start))
+                solo_total.add(teacher_forced([solo], prompt, enc_all[k:k + 1], Wb, rd, rules_solo, tol=0.15, margin=0.16, start=start))
+                solo_total.add(teacher_forced([beam1], prompt, enc_all[k:k + 1], Wb, rd, rules_solo, tol=0.15, margin=0.16, start=start))
     e.log_mel(clips, want_output=False)                                   # leave the module engine with the batch resident
     e.encode(B)
-    assert total.n_steps == 16 and total.n_clear >= 8, total              # not vacuous: most steps carried a clear margin
+    assert total.n_steps == len(rows) * n_graded and total.n_clear >= 0.6 * total.n_steps, total     # not vacuous
     assert solo_total.n_clear >= 4, solo_total
 
 
