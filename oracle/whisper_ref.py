@@ -162,10 +162,40 @@ def _gelu(x: torch.Tensor) -> torch.Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def _lin(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str) -> torch.Tensor:
+# Saturation of STORED activations (test-side switch, default off = the reference's f32 arithmetic).  The fp16 engine stores every
+# projection output as fp16 and clamps it to +-65504 on the way (common.hpp N16<f16_t>::sat; HF clamps its fp16 hidden states for the
+# same reason, [HF-M]:403-407); `with activation_clamp(65504.0):` makes this restatement clamp at the same places - the output of
+# every linear layer (q after its 1/8 scaling: the engine folds the scaling into the weights) and of the conv stem's first layer.
+_ACT_CLAMP: Optional[float] = None
+
+
+class activation_clamp:
+    def __init__(self, limit: Optional[float]):
+        self.limit = limit
+
+    def __enter__(self):
+        global _ACT_CLAMP
+        self.prev, _ACT_CLAMP = _ACT_CLAMP, self.limit
+        return self
+
+    def __exit__(self, *exc):
+        global _ACT_CLAMP
+        _ACT_CLAMP = self.prev
+        return False
+
+
+def _sat(y: torch.Tensor) -> torch.Tensor:
+    return y if _ACT_CLAMP is None else y.clamp(-_ACT_CLAMP, _ACT_CLAMP)
+
+
+def _lin(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str, scale: Optional[float] = None) -> torch.Tensor:
     y = x @ W[p + ".weight"].t()
     b = W.get(p + ".bias")
-    return y if b is None else y + b
+    if b is not None:
+        y = y + b
+    if scale is not None:
+        y = y * scale
+    return _sat(y)
 
 
 def _split_heads(x: torch.Tensor, H: int) -> torch.Tensor:
@@ -191,7 +221,7 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, mask: Optional[to
 def encoder_stem(mel: torch.Tensor, W: Dict[str, torch.Tensor]) -> torch.Tensor:
     """[B,M,2T] -> [B,T,d]: gelu(conv1 k3 s1 p1), gelu(conv2 k3 s2 p1), transpose, + positions
     ([HF-M]:618-624)."""
-    x = _gelu(F.conv1d(mel, W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], stride=1, padding=1))
+    x = _sat(_gelu(F.conv1d(mel, W["model.encoder.conv1.weight"], W["model.encoder.conv1.bias"], stride=1, padding=1)))
     x = _gelu(F.conv1d(x, W["model.encoder.conv2.weight"], W["model.encoder.conv2.bias"], stride=2, padding=1))
     x = x.permute(0, 2, 1)
     return x + W["model.encoder.embed_positions.weight"][None, : x.shape[1]]
@@ -201,7 +231,7 @@ def encoder_layer(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str, H: int) -
     """Pre-LN block, [HF-M]:380-413."""
     hd = x.shape[-1] // H
     h = _ln(x, W[p + ".self_attn_layer_norm.weight"], W[p + ".self_attn_layer_norm.bias"])
-    q = _split_heads(_lin(h, W, p + ".self_attn.q_proj") * (hd ** -0.5), H)
+    q = _split_heads(_lin(h, W, p + ".self_attn.q_proj", scale=hd ** -0.5), H)
     k = _split_heads(_lin(h, W, p + ".self_attn.k_proj"), H)
     v = _split_heads(_lin(h, W, p + ".self_attn.v_proj"), H)
     x = x + _lin(_attend(q, k, v), W, p + ".self_attn.out_proj")
@@ -265,7 +295,7 @@ def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, to
     for i in range(dims.dec_layers):
         p = f"model.decoder.layers.{i}"
         h = _ln(x, W[p + ".self_attn_layer_norm.weight"], W[p + ".self_attn_layer_norm.bias"])
-        q = _split_heads(_lin(h, W, p + ".self_attn.q_proj") * (hd ** -0.5), H)
+        q = _split_heads(_lin(h, W, p + ".self_attn.q_proj", scale=hd ** -0.5), H)
         k = _split_heads(_lin(h, W, p + ".self_attn.k_proj"), H)
         v = _split_heads(_lin(h, W, p + ".self_attn.v_proj"), H)
         if cache.k[i] is not None:
@@ -274,7 +304,7 @@ def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, to
         cache.k[i], cache.v[i] = k, v
         x = x + _lin(_attend(q, k, v, mask), W, p + ".self_attn.out_proj")
         h = _ln(x, W[p + ".encoder_attn_layer_norm.weight"], W[p + ".encoder_attn_layer_norm.bias"])
-        q = _split_heads(_lin(h, W, p + ".encoder_attn.q_proj") * (hd ** -0.5), H)
+        q = _split_heads(_lin(h, W, p + ".encoder_attn.q_proj", scale=hd ** -0.5), H)
         if cross_probs is not None:
             cross_probs.append(torch.softmax(q @ xkv[i][0].transpose(-1, -2), dim=-1))
         x = x + _lin(_attend(q, xkv[i][0], xkv[i][1]), W, p + ".encoder_attn.out_proj")

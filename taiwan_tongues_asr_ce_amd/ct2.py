@@ -62,9 +62,13 @@ class _Cursor:
         return struct.unpack("<I", self.take(4))[0]
 
     def string(self) -> str:
+        at = self.pos
         n = self.u16()
         raw = bytes(self.take(n))
-        return raw.rstrip(b"\0").decode("utf-8")
+        try:
+            return raw.rstrip(b"\0").decode("utf-8")
+        except UnicodeDecodeError as ex:
+            raise CT2FormatError(f"string at offset {at} is not UTF-8 ({ex.reason}): not a CTranslate2 model.bin?") from None
 
 
 def _bf16_to_f32(raw: np.ndarray) -> np.ndarray:
@@ -73,7 +77,10 @@ def _bf16_to_f32(raw: np.ndarray) -> np.ndarray:
 
 def read_model_bin(path: str) -> Tuple[str, int, Dict[str, np.ndarray], Dict[str, str]]:
     """-> (spec name, spec revision, {variable: array in its stored dtype (bf16 widened to f32)}, {alias: target})."""
-    buf = np.memmap(path, dtype=np.uint8, mode="r")
+    try:
+        buf = np.memmap(path, dtype=np.uint8, mode="r")
+    except ValueError as ex:          # an empty file cannot be mapped
+        raise CT2FormatError(f"{path}: {ex}") from None
     cur = _Cursor(buf)
     version = cur.u32()
     if version < 2 or version > 64:
@@ -82,7 +89,11 @@ def read_model_bin(path: str) -> Tuple[str, int, Dict[str, np.ndarray], Dict[str
     variables: Dict[str, np.ndarray] = {}
     for _ in range(cur.u32()):
         name = cur.string()
+        if name in variables:
+            raise CT2FormatError(f"variable {name!r} appears twice")
         rank = cur.u8()
+        if rank > 8:
+            raise CT2FormatError(f"{name}: rank {rank} (CTranslate2 tensors have at most a few dimensions: damaged header?)")
         shape = tuple(cur.u32() for _ in range(rank))
         if version >= 4:
             dtype_id, n_bytes = cur.u8(), cur.u32()
@@ -136,13 +147,24 @@ def write_model_bin(path: str, variables: Dict[str, np.ndarray], aliases: Option
 
 def _dense(variables: Dict[str, np.ndarray], aliases: Dict[str, str], name: str) -> Optional[np.ndarray]:
     """Float32 value of a possibly aliased / quantised variable."""
-    name = aliases.get(name, name)
+    seen = set()
+    while name in aliases:          # the format allows an alias of an alias; a cycle is damage
+        if name in seen:
+            raise CT2FormatError(f"alias cycle through {name!r}")
+        seen.add(name)
+        name = aliases[name]
     if name not in variables:
         return None
     v = variables[name]
     if v.dtype == np.int8 and name + "_scale" in variables:
         scale = np.asarray(variables[name + "_scale"], dtype=np.float32)
+        if scale.size not in (1, v.shape[0] if v.ndim else 1):
+            raise CT2FormatError(f"{name}_scale has {scale.size} entries for {v.shape[0] if v.ndim else 1} output rows")
+        if not np.all(np.isfinite(scale)) or np.any(scale == 0):
+            raise CT2FormatError(f"{name}_scale holds zeros / non-finite values")
         return v.astype(np.float32) / scale.reshape((-1,) + (1,) * (v.ndim - 1))
+    if v.dtype in (np.int8, np.int16, np.int32) and v.ndim >= 2 and name + "_scale" not in variables:
+        raise CT2FormatError(f"{name} is stored as {v.dtype} without a {name}_scale variable: cannot de-quantise")
     if v.dtype == np.int16 and name + "_scale" in variables:
         return v.astype(np.float32) / float(np.asarray(variables[name + "_scale"], dtype=np.float32).reshape(-1)[0])
     return np.asarray(v, dtype=np.float32)
@@ -155,18 +177,29 @@ def infer_dims(variables: Dict[str, np.ndarray], aliases: Dict[str, str], name: 
         if n not in variables:
             raise CT2FormatError(f"model.bin has no variable {n!r}: not a Whisper model?")
         return variables[n].shape
-    d_model, n_mels, _k = shape("encoder/conv1/weight")
-    n_audio_ctx = shape("encoder/position_encodings/encodings")[0]
-    vocab = shape("decoder/embeddings/weight")[0]
-    n_text_ctx = shape("decoder/position_encodings/encodings")[0]
-    ffn = shape("encoder/layer_0/ffn/linear_0/weight")[0]
+    def shape_of_rank(n, rank):
+        sh = shape(n)
+        if len(sh) != rank or any(x <= 0 for x in sh):
+            raise CT2FormatError(f"{n}: expected a rank-{rank} tensor with positive dimensions, got shape {sh}")
+        return sh
+    d_model, n_mels, _k = shape_of_rank("encoder/conv1/weight", 3)
+    if _k != 3:
+        raise CT2FormatError(f"encoder/conv1/weight: kernel width {_k}, Whisper's stem has 3")
+    n_audio_ctx = shape_of_rank("encoder/position_encodings/encodings", 2)[0]
+    vocab = shape_of_rank("decoder/embeddings/weight", 2)[0]
+    n_text_ctx = shape_of_rank("decoder/position_encodings/encodings", 2)[0]
+    ffn = shape_of_rank("encoder/layer_0/ffn/linear_0/weight", 2)[0]
     enc_layers = dec_layers = 0
     while f"encoder/layer_{enc_layers}/ffn/linear_0/weight" in variables:
         enc_layers += 1
     while f"decoder/layer_{dec_layers}/ffn/linear_0/weight" in variables:
         dec_layers += 1
     heads = variables.get("encoder/num_heads")
-    n_heads = int(np.asarray(heads).reshape(-1)[0]) if heads is not None else d_model // 64
+    n_heads = int(np.asarray(heads).reshape(-1)[0]) if heads is not None and np.asarray(heads).size else d_model // 64
+    if n_heads <= 0 or d_model % n_heads or d_model // n_heads != 64:
+        raise CT2FormatError(f"{n_heads} heads for d_model {d_model}: every Whisper checkpoint has head_dim 64")
+    if dec_layers == 0:
+        raise CT2FormatError("model.bin has no decoder/layer_0: not a Whisper model?")
     return WhisperDims(name, n_mels, n_audio_ctx, d_model, n_heads, ffn, enc_layers, dec_layers, vocab, n_text_ctx)
 
 
@@ -192,6 +225,8 @@ def iter_hf_tensors(variables: Dict[str, np.ndarray], aliases: Dict[str, str], d
         w, b = get(ct2 + "/linear_0/weight"), get(ct2 + "/linear_0/bias")
         if w.shape != (3 * d, d):
             raise CT2FormatError(f"{ct2}/linear_0/weight: expected fused q/k/v {(3 * d, d)}, got {w.shape}")
+        if b.shape != (3 * d,):
+            raise CT2FormatError(f"{ct2}/linear_0/bias: expected fused q/k/v ({3 * d},), got {b.shape}")
         yield hf + ".q_proj.weight", w[:d]
         yield hf + ".q_proj.bias", b[:d]
         yield hf + ".k_proj.weight", w[d:2 * d]        # Whisper's k projection has no bias (the fused slot is zeros)
@@ -225,6 +260,8 @@ def iter_hf_tensors(variables: Dict[str, np.ndarray], aliases: Dict[str, str], d
         w, b = get(c + "/attention/linear_1/weight"), get(c + "/attention/linear_1/bias")
         if w.shape != (2 * d, d):
             raise CT2FormatError(f"{c}/attention/linear_1/weight: expected fused k/v {(2 * d, d)}, got {w.shape}")
+        if b.shape != (2 * d,):
+            raise CT2FormatError(f"{c}/attention/linear_1/bias: expected fused k/v ({2 * d},), got {b.shape}")
         yield h + ".encoder_attn.k_proj.weight", w[:d]
         yield h + ".encoder_attn.v_proj.weight", w[d:]
         yield h + ".encoder_attn.v_proj.bias", b[d:]

@@ -126,3 +126,150 @@ def test_reader_against_the_independent_int8_writer(tmp_path):
         err = np.abs(got[k] - hf[k]).max()
         assert err <= np.abs(hf[k]).max() * (1.0 / 127 if hf[k].ndim == 2 else 2e-3) + 1e-6, (k, err)   # and close to the originals
     assert cfg["alignment_heads"] == [[1, 0]]
+
+
+# ---- malformed files: whatever is wrong with an operator's model.bin, the reader answers with
+# CT2FormatError - never a crash with another exception type, never a silent mis-load --------------------------------------
+def _s(t):
+    raw = t if isinstance(t, bytes) else t.encode()
+    return struct.pack("<H", len(raw) + 1) + raw + b"\0"
+
+
+def _var(name, arr, dtype_id=None, n_bytes=None, shape=None):
+    arr = np.ascontiguousarray(arr)
+    shape = arr.shape if shape is None else shape
+    data = arr.tobytes()
+    ids = {"float32": 0, "int8": 1, "int16": 2, "int32": 3, "float16": 4}
+    return (_s(name) + struct.pack("<B", len(shape)) + b"".join(struct.pack("<I", x) for x in shape)
+            + struct.pack("<B", ids[arr.dtype.name] if dtype_id is None else dtype_id)
+            + struct.pack("<I", len(data) if n_bytes is None else n_bytes) + data)
+
+
+def _file(variables=(), aliases=(), version=6, spec="WhisperSpec", n_vars=None, n_aliases=None):
+    out = struct.pack("<I", version) + _s(spec) + struct.pack("<I", 3) + struct.pack("<I", len(variables) if n_vars is None else n_vars)
+    out += b"".join(variables)
+    out += struct.pack("<I", len(aliases) if n_aliases is None else n_aliases) + b"".join(_s(a) + _s(t) for a, t in aliases)
+    return out
+
+
+_F4 = np.arange(6, dtype="<f4").reshape(2, 3)
+MALFORMED_BIN = {
+    "empty file": (b"", "empty|mmap|truncated"),
+    "header cut inside the version": (b"\x06\x00", "truncated"),
+    "header cut inside the spec name": (struct.pack("<I", 6) + struct.pack("<H", 12) + b"Whisp", "truncated"),
+    "variable count says more than the file holds": (_file([_var("a", _F4)], n_vars=3), "truncated"),
+    "absurd variable count": (_file([], n_vars=0xFFFFFFFF), "truncated"),
+    "data cut short": (_file([_var("a", _F4)])[:-20], "truncated"),
+    "unknown dtype id": (_file([_var("a", _F4, dtype_id=9)]), "unknown dtype id 9"),
+    "shape x itemsize != byte count": (_file([_var("a", _F4, shape=(2, 4))]), r"shape \(2, 4\) x 4 B != 24 B"),
+    "byte count larger than the data": (_file([_var("a", _F4, n_bytes=4000)]), "truncated|!="),
+    "rank byte is garbage": (_file([_s("a") + struct.pack("<B", 200) + b"\0" * 64]), "rank 200"),
+    "name is not UTF-8": (_file([_var(b"\xff\xfe\xfa", _F4)]), "not UTF-8"),
+    "the same variable twice": (_file([_var("a", _F4), _var("a", _F4)]), "appears twice"),
+    "alias table cut short": (_file([_var("a", _F4)], aliases=[("b", "a")], n_aliases=2), "truncated"),
+    "future binary version": (_file([_var("a", _F4)], version=4096), "binary version 4096"),
+}
+
+
+@pytest.mark.parametrize("what", sorted(MALFORMED_BIN))
+def test_malformed_model_bin_always_raises_ct2_format_error(tmp_path, what):
+    raw, match = MALFORMED_BIN[what]
+    p = tmp_path / "model.bin"
+    p.write_bytes(raw)
+    with pytest.raises(ct2.CT2FormatError, match=match):
+        ct2.read_model_bin(str(p))
+    with pytest.raises(ct2.CT2FormatError):
+        ct2.read_ct2_dir(str(tmp_path))
+
+
+def _whisper_vars():
+    return ct2.hf_to_ct2(_hf().items(), DIMS)
+
+
+def _drop(name):
+    def f(v, a):
+        del v[name]
+    return f
+
+
+def _set(name, value):
+    def f(v, a):
+        v[name] = value
+    return f
+
+
+def _alias(alias, target):
+    def f(v, a):
+        a[alias] = target
+    return f
+
+
+_D = DIMS.d_model
+MALFORMED_WHISPER = {
+    # (edit of a valid WhisperSpec variable set, expected message)
+    "no conv stem": (_drop("encoder/conv1/weight"), "no variable 'encoder/conv1/weight'"),
+    "conv weight of the wrong rank": (_set("encoder/conv1/weight", np.zeros((_D, DIMS.n_mels), np.float32)), "rank-3"),
+    "conv kernel of the wrong width": (_set("encoder/conv1/weight", np.zeros((_D, DIMS.n_mels, 5), np.float32)), "kernel width 5"),
+    "head count that does not give head_dim 64": (_set("encoder/num_heads", np.asarray(3, np.int16)), "head_dim 64"),
+    "alias whose target is absent": (lambda v, a: (v.pop("decoder/layer_norm/gamma"), a.__setitem__("decoder/layer_norm/gamma", "nowhere/gamma")),
+                                     "missing 'decoder/layer_norm/gamma'"),
+    "alias cycle": (lambda v, a: (v.pop("decoder/layer_norm/beta"), a.__setitem__("decoder/layer_norm/beta", "x"), a.__setitem__("x", "decoder/layer_norm/beta")),
+                    "alias cycle"),
+    "self-attention not fused (separate q only)": (_set("encoder/layer_0/self_attention/linear_0/weight", np.zeros((_D, _D), np.float32)),
+                                                   "expected fused q/k/v"),
+    "fused q/k/v weight with an unfused bias": (_set("decoder/layer_1/self_attention/linear_0/bias", np.zeros(_D, np.float32)),
+                                                 r"linear_0/bias: expected fused q/k/v"),
+    "linear_0 missing altogether": (_drop("decoder/layer_0/self_attention/linear_0/weight"), "missing 'decoder/layer_0/self_attention/linear_0/weight'"),
+    "cross-attention k/v not fused": (_set("decoder/layer_0/attention/linear_1/weight", np.zeros((_D, _D), np.float32)), "expected fused k/v"),
+    "cross-attention k/v bias of the wrong length": (_set("decoder/layer_0/attention/linear_1/bias", np.zeros(_D, np.float32)), r"linear_1/bias: expected fused k/v"),
+    "int8 weight without its scale": (_set("encoder/layer_0/ffn/linear_0/weight", np.zeros((DIMS.ffn_dim, _D), np.int8)), "without a .*_scale"),
+    "int8 scale of the wrong length": (lambda v, a: (v.__setitem__("encoder/layer_0/ffn/linear_0/weight", np.ones((DIMS.ffn_dim, _D), np.int8)),
+                                                    v.__setitem__("encoder/layer_0/ffn/linear_0/weight_scale", np.ones(7, np.float32))), "_scale has 7 entries"),
+    "int8 scale holding a zero": (lambda v, a: (v.__setitem__("encoder/layer_0/ffn/linear_0/weight", np.ones((DIMS.ffn_dim, _D), np.int8)),
+                                               v.__setitem__("encoder/layer_0/ffn/linear_0/weight_scale", np.zeros(DIMS.ffn_dim, np.float32))), "zeros / non-finite"),
+    "a layer norm without its beta": (_drop("encoder/layer_1/ffn/layer_norm/beta"), "missing 'encoder/layer_1/ffn/layer_norm/beta'"),
+    "no decoder layers": (lambda v, a: [v.pop(k) for k in list(v) if k.startswith("decoder/layer_")], "no decoder/layer_0"),
+    "untied output projection": (lambda v, a: (a.pop("decoder/projection/weight"), v.__setitem__("decoder/projection/weight", v["decoder/embeddings/weight"] + 1)),
+                                 "untied output projection"),
+}
+
+
+@pytest.mark.parametrize("what", sorted(MALFORMED_WHISPER))
+def test_malformed_whisper_spec_always_raises_ct2_format_error(tmp_path, what):
+    edit, match = MALFORMED_WHISPER[what]
+    variables, aliases = _whisper_vars()
+    edit(variables, aliases)
+    ct2.write_model_bin(str(tmp_path / "model.bin"), variables, aliases)
+    with pytest.raises(ct2.CT2FormatError, match=match):
+        dims, tensors, _ = ct2.read_ct2_dir(str(tmp_path))
+        dict(tensors)                    # the tensor stream is lazy: consume it
+
+
+def test_random_byte_damage_never_escapes_as_another_exception(tmp_path):
+    """400 random single-byte corruptions and 100 random truncations of a valid file: the reader returns or raises
+    CT2FormatError - nothing else (IndexError, struct.error, MemoryError, UnicodeDecodeError ...)."""
+    variables, aliases = _whisper_vars()
+    ct2.write_model_bin(str(tmp_path / "good.bin"), variables, aliases)
+    good = (tmp_path / "good.bin").read_bytes()
+    # the header / name / shape bytes are where damage matters: pick offsets from the first variable records and the alias table
+    rng = np.random.default_rng(5)
+    d = tmp_path / "m"; d.mkdir()
+    hot = np.concatenate([rng.integers(0, 4096, size=250), rng.integers(len(good) - 200, len(good), size=150)])
+    n_raised = 0
+    for i, off in enumerate(hot):
+        bad = bytearray(good)
+        bad[int(off)] ^= int(rng.integers(1, 256))
+        (d / "model.bin").write_bytes(bytes(bad))
+        try:
+            _, tensors, _ = ct2.read_ct2_dir(str(d))
+            for _ in tensors:
+                pass
+        except ct2.CT2FormatError:
+            n_raised += 1
+    for cut in rng.integers(1, len(good), size=100):
+        (d / "model.bin").write_bytes(good[:int(cut)])
+        with pytest.raises(ct2.CT2FormatError):
+            _, tensors, _ = ct2.read_ct2_dir(str(d))
+            for _ in tensors:
+                pass
+    assert n_raised > 20      # the corruption did hit structure, not only payload bytes

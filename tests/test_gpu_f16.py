@@ -246,3 +246,78 @@ def test_f16_full_depth_b32_tokens_equal_the_f32_parity_engine():
     for r in range(B):
         if same[r]:
             assert abs(float(a.sum_logprob[r]) - float(b.sum_logprob[r])) < 0.02 * n_new, r
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# fp16 SATURATION (ADVICE round 3 / VERDICT round 4, next #5).  fp16 is what compute_type "default" / "float16" and the
+# streaming adapter run (model.py, asr.py), so an activation beyond +-65504 must not become inf -> NaN in the next LayerNorm /
+# softmax.  Every 16-bit store of the engine clamps (common.hpp N16<f16_t>::sat); the oracle reproduces the clamp at the same
+# places (`R.activation_clamp`: every linear-layer output, q after its 1/8 scaling, the stem's first convolution).
+def _scaled_state_dict(dims, scales):
+    sd = dict(synth.state_dict(dims))
+    for prefix, s in scales.items():
+        for suffix in (".weight", ".bias"):
+            if prefix + suffix in sd:
+                sd[prefix + suffix] = (sd[prefix + suffix] * np.float32(s)).astype(np.float32)
+    return sd
+
+
+# v / fc1 of one encoder layer and of the first decoder layer (self v, cross v, fc1): pre-activation std 5e4 / 1.2e5, i.e. 19 % of
+# the v entries and 58 % of the fc1 entries lie beyond 65504 before the clamp; the clamped out-proj / fc2 outputs then reach
+# +-65504 themselves (the residual stream - f32 in the engine - peaks at 131 008).  The weights stay fp16-representable (< 3e4).
+SAT_VALUES = {"model.encoder.layers.1.self_attn.v_proj": 5e4, "model.encoder.layers.1.fc1": 1.2e5,
+              "model.decoder.layers.0.self_attn.v_proj": 5e4, "model.decoder.layers.0.encoder_attn.v_proj": 5e4,
+              "model.decoder.layers.0.fc1": 1.2e5}
+# ... plus the QUERIES: |q| ~ 2e4 with a tail past 65504.  Scores are then ~1e5 and every softmax is one-hot; fp16 stores such a q
+# with an ulp of 16-32, i.e. the scores are known to +-100s and the winning key of a row is not determined by the arithmetic type's
+# precision - no fp16 implementation (HF's included) agrees with an f32 evaluation there, so this case asserts what saturation is
+# FOR: finite, deterministic output.
+SAT_QUERIES = dict(SAT_VALUES, **{"model.encoder.layers.1.self_attn.q_proj": 1.6e5, "model.decoder.layers.0.self_attn.q_proj": 1.6e5,
+                                 "model.decoder.layers.0.encoder_attn.q_proj": 1.6e5})
+
+
+@pytest.mark.parametrize("case", ["control", "values", "queries"])
+def test_f16_saturates_instead_of_overflowing(case):
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    dims = PRESETS["tiny"]
+    rd = R.Dims(**dims.as_dict())
+    sd = _scaled_state_dict(dims, {"control": {}, "values": SAT_VALUES, "queries": SAT_QUERIES}[case])
+    clips = [synth.noise_clip(5), synth.tonal_clip(6)]
+    e = Engine(dims, COMPUTE_F16, 2)
+    e.load_weights(sd.items())
+    st = e.special
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    e.log_mel(clips, want_output=False)
+    enc = e.encode(2, want_output=True)
+    e.decode_reset(2)
+    logits = [e.decode_step([t] * 2) for t in prompt + [1234, 777]]
+    res = e.generate([prompt] * 2, e.gen_opts(12, False, suppress_eot=True))
+    # finite everywhere, and reproducible
+    assert np.isfinite(enc).all() and all(np.isfinite(l).all() for l in logits) and np.isfinite(res.sum_logprob).all()
+    assert all(len(t) == 12 for t in res.tokens)
+    again = e.generate([prompt] * 2, e.gen_opts(12, False, suppress_eot=True))
+    assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
+    e.close()
+    if case == "queries":
+        return
+    W = R.to_torch(sd, round_f16=True)
+    mel = torch.from_numpy(np.stack([R.log_mel(c, dims.n_mels) for c in clips]))
+
+    def oracle(limit):
+        with R.activation_clamp(limit):
+            enc_ref = R.encoder_forward(mel, W, rd)
+            xkv = R.cross_kv(enc_ref, W, rd)
+            cache = R.SelfCache.empty(rd.dec_layers)
+            lg = [R.decoder_forward(torch.full((2, 1), t), cache, xkv, W, rd)[:, 0].numpy() for t in prompt + [1234, 777]]
+        return enc_ref.numpy(), lg
+    enc_ref, lg_ref = oracle(65504.0)
+    err_enc = np.abs(enc - enc_ref)
+    err_lg = max(float(np.abs(a - b).max()) for a, b in zip(logits, lg_ref))
+    # the same tolerances as the unsaturated fp16 gates of this file (encoder 0.04 on LayerNorm-scale values, logits 0.015 x 2:
+    # two more positions than the golden test, self-attention over cached saturated values)
+    assert err_enc.max() < 0.04 and err_enc.mean() < 0.004, (case, float(err_enc.max()), float(err_enc.mean()))
+    assert err_lg < 0.03, (case, err_lg)
+    if case == "values":       # the clamp is what is being tested: WITHOUT it the same oracle is somewhere else entirely
+        enc_nc, lg_nc = oracle(None)
+        assert float(np.abs(enc_ref - enc_nc).max()) > 0.5
+        assert float(np.abs(enc - enc_nc).max()) > 0.5

@@ -35,3 +35,28 @@ def test_causal_grader_matches_stepwise_and_rejects_a_wrong_token(ts):
     bad[3][7] = (bad[3][7] + 1) % 400 + 10
     with pytest.raises(AssertionError, match="row 3 step 7"):
         teacher_forced_causal(bad, prompt, enc, W, rd, rules, tol=1e-4, margin=1e-4)
+
+
+def test_oracle_activation_clamp_is_off_by_default_and_clamps_when_asked():
+    """`R.activation_clamp` (used by the fp16 saturation test): no effect on unsaturated activations, restores the previous state,
+    and clamps every linear output (q after its scaling) when the weights push them past the limit."""
+    d = PRESETS["micro"]
+    rd = R.Dims(**d.as_dict())
+    sd = dict(synth.state_dict(d))
+    n = d.n_frames * 160
+    mel = torch.from_numpy(R.log_mel(synth.noise_clip(1, n), d.n_mels, n))[None]
+    W = R.to_torch(sd)
+    base = R.encoder_forward(mel, W, rd)
+    with R.activation_clamp(65504.0):
+        same = R.encoder_forward(mel, W, rd)
+    assert torch.equal(base, same) and R._ACT_CLAMP is None
+    sd["model.encoder.layers.0.fc1.weight"] = sd["model.encoder.layers.0.fc1.weight"] * np.float32(1e6)
+    W2 = R.to_torch(sd)
+    free = R.encoder_forward(mel, W2, rd)
+    with R.activation_clamp(65504.0):
+        clamped = R.encoder_forward(mel, W2, rd)
+    assert torch.isfinite(clamped).all() and float((free - clamped).abs().max()) > 0.1
+    x = torch.tensor([[1e9, -1e9, 3.0]])
+    with R.activation_clamp(10.0):
+        assert R._sat(x).tolist() == [[10.0, -10.0, 3.0]]
+    assert R._sat(x).tolist() == x.tolist()

@@ -110,3 +110,37 @@ def test_silero_shaped_network_is_driven_frame_by_frame_with_context_and_state()
     assert not seen[-1][0][0, 64 + (len(audio) - (n - 1) * 512):].any()            # zero-padded tail
     chunks = vad.get_speech_timestamps(audio, vad.VadOptions(min_silence_duration_ms=300, speech_pad_ms=0), fn)
     assert len(chunks) == 1 and abs(chunks[0]["start"] - 16000) <= 512 and abs(chunks[0]["end"] - 32000) <= 1024
+
+
+def test_silero_adapter_contract_edge_cases():
+    """More of the documented contract of vad.silero_speech_prob_fn (vad.py:52-75), recorded by a fake `step` (VERDICT round 4,
+    next #8): the frames tile the recording exactly (nothing dropped, nothing doubled), a recording whose length is a multiple of
+    512 gets no extra frame, every recording starts from a ZERO state and ZERO context (nothing leaks from the previous call),
+    the state the network returns is the very object handed to the next call, an empty recording makes no call, and the
+    context length / state shape are the caller's (Silero v4 graphs: no context, [2, 1, 64] state)."""
+    from taiwan_tongues_asr_ce_amd import vad
+    calls = []
+
+    def step(x, h):
+        calls.append((x.copy(), h))
+        return 0.25 + 0.5 * (len(calls) % 2), h + 1.0
+    fn = vad.silero_speech_prob_fn(step)
+    rng = np.random.default_rng(0)
+    for n_samples in (512 * 7, 512 * 7 + 1, 511, 1):
+        calls.clear()
+        audio = rng.standard_normal(n_samples).astype(np.float32)
+        probs = fn(audio)
+        n = -(-n_samples // 512)
+        assert probs.shape == (n,) and probs.dtype == np.float32 and len(calls) == n
+        body = np.concatenate([x[0, 64:] for x, _ in calls])
+        np.testing.assert_array_equal(body[:n_samples], audio)                     # the frames tile the recording
+        assert not body[n_samples:].any()                                          # and only zeros pad the last one
+        assert not calls[0][0][0, :64].any() and not calls[0][1].any()             # fresh context + state per recording
+        for i in range(1, n):
+            assert float(calls[i][1][0, 0, 0]) == float(i)                         # what step returned is what step gets
+        np.testing.assert_allclose(probs, [0.25 + 0.5 * ((i + 1) % 2) for i in range(n)])
+    calls.clear()
+    assert fn(np.zeros(0, np.float32)).shape == (0,) and not calls
+    v4 = vad.silero_speech_prob_fn(lambda x, h: (calls.append((x.shape, h.shape)) or 0.0, h), context=0, state_shape=(2, 1, 64))
+    v4(np.ones(1000, np.float32))
+    assert calls == [((1, 512), (2, 1, 64))] * 2
