@@ -618,7 +618,7 @@ def main():
         # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent; static, like traffic)
         pmc_busy, pmc_file, pmc_note = None, None, None
         try:
-            pmc_file = next(f_ for f_ in ("r4_pmc.json", "r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            pmc_file = next(f_ for f_ in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc_busy, pmc_note = pmc_busy_from_profile(json.load(f)["kernels"], [x.get("signature") for x in gs], [x["flops"] for x in gs])
         except Exception as ex:

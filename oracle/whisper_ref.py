@@ -166,21 +166,25 @@ def _gelu(x: torch.Tensor) -> torch.Tensor:
 # projection output as fp16 and clamps it to +-65504 on the way (common.hpp N16<f16_t>::sat; HF clamps its fp16 hidden states for the
 # same reason, [HF-M]:403-407); `with activation_clamp(65504.0):` makes this restatement clamp at the same places - the output of
 # every linear layer (q after its 1/8 scaling: the engine folds the scaling into the weights) and of the conv stem's first layer.
+# The decoder's out-proj / fc2 outputs are the exception when `decoder_residual=False`: the engine's decode STEP never stores them
+# in 16 bits (their K-split f32 partial tiles are added straight into the f32 residual stream), so nothing clamps them there.
 _ACT_CLAMP: Optional[float] = None
+_ACT_CLAMP_DEC_RESIDUAL: bool = True
 
 
 class activation_clamp:
-    def __init__(self, limit: Optional[float]):
-        self.limit = limit
+    def __init__(self, limit: Optional[float], decoder_residual: bool = True):
+        self.limit, self.dec_res = limit, decoder_residual
 
     def __enter__(self):
-        global _ACT_CLAMP
-        self.prev, _ACT_CLAMP = _ACT_CLAMP, self.limit
+        global _ACT_CLAMP, _ACT_CLAMP_DEC_RESIDUAL
+        self.prev = (_ACT_CLAMP, _ACT_CLAMP_DEC_RESIDUAL)
+        _ACT_CLAMP, _ACT_CLAMP_DEC_RESIDUAL = self.limit, self.dec_res
         return self
 
     def __exit__(self, *exc):
-        global _ACT_CLAMP
-        _ACT_CLAMP = self.prev
+        global _ACT_CLAMP, _ACT_CLAMP_DEC_RESIDUAL
+        _ACT_CLAMP, _ACT_CLAMP_DEC_RESIDUAL = self.prev
         return False
 
 
@@ -188,14 +192,16 @@ def _sat(y: torch.Tensor) -> torch.Tensor:
     return y if _ACT_CLAMP is None else y.clamp(-_ACT_CLAMP, _ACT_CLAMP)
 
 
-def _lin(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str, scale: Optional[float] = None) -> torch.Tensor:
+def _lin(x: torch.Tensor, W: Dict[str, torch.Tensor], p: str, scale: Optional[float] = None, dec_residual: bool = False
+         ) -> torch.Tensor:
+    """dec_residual: this is a decoder out-proj / fc2 (its output is added to the residual stream)."""
     y = x @ W[p + ".weight"].t()
     b = W.get(p + ".bias")
     if b is not None:
         y = y + b
     if scale is not None:
         y = y * scale
-    return _sat(y)
+    return y if (dec_residual and not _ACT_CLAMP_DEC_RESIDUAL) else _sat(y)
 
 
 def _split_heads(x: torch.Tensor, H: int) -> torch.Tensor:
@@ -302,14 +308,14 @@ def decoder_forward(tokens: torch.Tensor, cache: SelfCache, xkv, W: Dict[str, to
             k = torch.cat([cache.k[i], k], dim=2)
             v = torch.cat([cache.v[i], v], dim=2)
         cache.k[i], cache.v[i] = k, v
-        x = x + _lin(_attend(q, k, v, mask), W, p + ".self_attn.out_proj")
+        x = x + _lin(_attend(q, k, v, mask), W, p + ".self_attn.out_proj", dec_residual=True)
         h = _ln(x, W[p + ".encoder_attn_layer_norm.weight"], W[p + ".encoder_attn_layer_norm.bias"])
         q = _split_heads(_lin(h, W, p + ".encoder_attn.q_proj", scale=hd ** -0.5), H)
         if cross_probs is not None:
             cross_probs.append(torch.softmax(q @ xkv[i][0].transpose(-1, -2), dim=-1))
-        x = x + _lin(_attend(q, xkv[i][0], xkv[i][1]), W, p + ".encoder_attn.out_proj")
+        x = x + _lin(_attend(q, xkv[i][0], xkv[i][1]), W, p + ".encoder_attn.out_proj", dec_residual=True)
         h = _ln(x, W[p + ".final_layer_norm.weight"], W[p + ".final_layer_norm.bias"])
-        x = x + _lin(_gelu(_lin(h, W, p + ".fc1")), W, p + ".fc2")
+        x = x + _lin(_gelu(_lin(h, W, p + ".fc1")), W, p + ".fc2", dec_residual=True)
     x = _ln(x, W["model.decoder.layer_norm.weight"], W["model.decoder.layer_norm.bias"])
     return x @ W["model.decoder.embed_tokens.weight"].t()  # proj_out tied, [HF-M]:965,970
 

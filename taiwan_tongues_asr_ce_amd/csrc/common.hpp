@@ -51,7 +51,13 @@ template <> struct N16<f16_t> {
   // fp16 hidden states for the same reason (modeling_whisper.py:403-407).  ONE v_med3_f32 per value (the compare / max / min /
   // select form that also kept a NaN a NaN cost 3.6 ms per encoder pass at large-v3: 128 values per lane and GEMM tile); med3
   // maps a NaN input to -65504, so a NaN can no longer be used to spot an upstream fault in the fp16 mode.
+  // Lab builds (make EXTRA=-DTTASR_EXPERIMENTS) keep a NaN a NaN (one more v_cmp + v_cndmask per value), so that an upstream
+  // numerical fault still surfaces as NaN logits when the fp16 mode is being debugged; the release build does not.
+#ifdef TTASR_EXPERIMENTS
+  static __device__ __forceinline__ float sat(float v) { return v != v ? v : __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+#else
   static __device__ __forceinline__ float sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
+#endif
   static __device__ __forceinline__ uint32_t pk(float lo, float hi) {   // round-to-nearest-even, one v_cvt_pk_f16_f32
     typedef float f32x2_hw __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_hw){sat(lo), sat(hi)}, h16x2_hw));
@@ -171,6 +177,12 @@ struct GemmArgs {
   int64_t lda = 0, ldw = 0;
   int64_t batch_stride_a = 0;
   int batch = 1;
+  // groups > 1 (persistent 256 x 256 kernel only): `groups` GEMMs that share A and differ in W / bias / output - group g uses
+  // W + g * group_stride_w, bias + g * N and writes at out + g * group_stride_out (elements); the tiles of group 0 come first,
+  // then group 1 ...: one launch walks all of them, so only the LAST group ends in a partial round of workgroups (the 32
+  // cross-KV projections of the decoder layers: 60 160 tiles = 235.0 rounds of 256 instead of 32 x 8)
+  int groups = 1;
+  int64_t group_stride_w = 0, group_stride_out = 0;
   GemmEpi epi;
 };
 

@@ -100,6 +100,11 @@ int build_weights(ttasr_ctx* c) {
   add_slot(c, "model.decoder.embed_tokens.weight", c->emb, V, d, 0);
   add_slot(c, "model.decoder.embed_positions.weight", c->dpos, c->cfg.n_text_ctx, d, 0);
   c->dec.resize(c->cfg.dec_layers);
+  // the cross-attention K / V projections of ALL decoder layers as one [layers][2 d][d] block (+ biases [layers][2 d]): the
+  // cross-KV build walks them as one grouped GEMM (run_cross_kv), whose groups are a fixed stride apart
+  void* xkv_w_all = nullptr; float* xkv_b_all = nullptr;
+  TRY(alloc_mat(c, &xkv_w_all, (int64_t)c->cfg.dec_layers * 2 * d * d));
+  TRY(alloc_vec(c, &xkv_b_all, (int64_t)c->cfg.dec_layers * 2 * d));
   for (int i = 0; i < c->cfg.dec_layers; ++i) {
     std::string p = "model.decoder.layers." + std::to_string(i);
     DecLayerW& L = c->dec[i];
@@ -110,7 +115,7 @@ int build_weights(ttasr_ctx* c) {
     TRY(alloc_mat(c, &L.wqx, (int64_t)d * d)); TRY(alloc_vec(c, &L.bqx, d));
     add_slot(c, p + ".encoder_attn.q_proj.weight", L.wqx, d, d, 0, 0.125f);
     add_slot(c, p + ".encoder_attn.q_proj.bias", L.bqx, d, 1, 1, 0.125f);
-    TRY(alloc_mat(c, &L.wkvx, (int64_t)2 * d * d)); TRY(alloc_vec(c, &L.bkvx, 2 * d));
+    L.wkvx = off(xkv_w_all, (int64_t)i * 2 * d * d); L.bkvx = xkv_b_all + (int64_t)i * 2 * d;
     add_slot(c, p + ".encoder_attn.k_proj.weight", L.wkvx, d, d, 0);
     add_slot(c, p + ".encoder_attn.v_proj.weight", off(L.wkvx, (int64_t)d * d), d, d, 0);
     add_slot(c, p + ".encoder_attn.v_proj.bias", L.bkvx + d, d, 1, 1);

@@ -116,6 +116,7 @@ struct ttasr_ctx {
   int B_mel = 0, B_enc = 0, B_dec = 0;
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
   int xattn_nt = 1, xattn_pipe = 1, weights_nt = 1;  // options xattn_nontemporal / xattn_pipeline / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
+  bool xkv_grouped = true;  // option xkv_grouped = 0: one cross-KV GEMM launch per decoder layer instead of one grouped launch (A/B testing; bit-identical)
   bool multi_step = true;   // option multi_step_graph = 0: one graph replay per decode step (A/B testing)
   bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)
   bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)

@@ -52,13 +52,32 @@ void enc_mark(ttasr_ctx* c, int cls) {   // cls < 0: the start mark
 
 template <typename T>
 int run_cross_kv(ttasr_ctx* c, int B) {
-  const int d = c->d, T_ = c->T;
-  for (int l = 0; l < c->cfg.dec_layers; ++l) {
+  const int d = c->d, T_ = c->T, L = c->cfg.dec_layers;
+  auto layer_args = [&](int l) {
     GemmArgs g = lin_args<T>(c->enc_out, c->dec[l].wkvx, B * T_, 2 * d, d);
     g.epi.bias = c->dec[l].bkvx;
     g.epi.out_t = (char*)c->xkv + (size_t)l * c->xkv_layer_elems * c->esz;
     g.epi.headsplit = 1; g.epi.hs_T = T_; g.epi.hs_H = c->H; g.epi.hs_d = d; g.epi.hs_which = c->xkv_which_elems;
-    gemm<T>(c, g);
+    return g;
+  };
+  // Round 5: the L projections share A (the encoder output) and their weights / biases / outputs are a fixed stride apart
+  // (build_weights), so the persistent 256 x 256 kernel walks all L x tiles as ONE launch: at large-v3, B = 32 that is 60 160
+  // tiles = 235.0 rounds of 256 workgroups instead of 32 launches x 8 rounds (7.34 rounded up).  Same tiles, same arithmetic
+  // per tile: bit-identical to the per-layer launches (option xkv_grouped = 0).
+  bool grouped = false;
+  if constexpr (sizeof(T) == 2) {
+    GemmArgs g = layer_args(0);
+    const int64_t tiles = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * L;
+    if (c->xkv_grouped && L > 1 && !c->force_basic && c->gemm_persistent && (c->gemm_force == 0 || c->gemm_force == 4) && g.M >= 256 &&
+        tiles >= 512 && gemm_bf16_v4_ok(g)) {
+      g.groups = L; g.group_stride_w = (int64_t)2 * d * d; g.group_stride_out = c->xkv_layer_elems;
+      launch_gemm_bf16_v4<T>(g, c->cur);
+      grouped = true;
+      enc_mark(c, EC_XKV);
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    if (!grouped) gemm<T>(c, layer_args(l));
     if constexpr (sizeof(T) == 2) {
       if (c->xkv_fp8 && c->xkv8) {   // quantise this layer's K and V blocks of the B clips (one workgroup per (clip, head) block)
         for (int which = 0; which < 2; ++which) {
@@ -68,7 +87,7 @@ int run_cross_kv(ttasr_ctx* c, int B) {
         }
       }
     }
-    enc_mark(c, EC_XKV);
+    if (!grouped || (c->xkv_fp8 && c->xkv8)) enc_mark(c, EC_XKV);
   }
   c->xkv8_valid = c->xkv_fp8 && c->xkv8 != nullptr && sizeof(T) == 2;
   return 0;
@@ -172,6 +191,10 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
     // 32-row group; wider batches (beam search, streaming: 33-128 rows) keep the automatic choice, whose k-steps per wave fit the
     // straight-line form (2 slices there meant the looped form: 10.4 us at 40 rows)
     if (kind == 2 && want == 0 && n <= 32 && (N + 31) / 32 >= 96) want = 2;
+    // out-proj at d = 1280 with one 32-row group: 5 slices (200 workgroups x 4 k-steps per wave) instead of the automatic 4 (160 x 5)
+    // measured 2.8438 vs 2.8494 ms per decode step in two interleaved rounds (round 5; `tools/decode_variants.py
+    // --variants auto,d5`): kept.  The q GEMM stays at 4: the attention consumers sum at most 4 slabs.
+    if (kind == 0 && want == 0 && n <= 32 && K == 1280 && N == 1280) want = 5;
     int ks = gemm_skinny_ksplit(n, N, K, want);
     if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
     return ks;

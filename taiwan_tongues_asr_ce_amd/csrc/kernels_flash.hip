@@ -60,35 +60,67 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   const bf16_t* kbase = CROSS ? kx + ((int64_t)b * H + h) * n_k * 64 : base + d;
   const bf16_t* vbase = CROSS ? vx + ((int64_t)b * H + h) * n_k * 64 : base + 2 * d;
 
-  // Q fragments (B operand of S^T): lane holds Q[q0 + r][16*ks + 8*hf .. +8]
+  // Q fragments (B operand of S^T): lane holds Q[q0 + r][16*ks + 8*hf .. +8], multiplied by log2(e) ONCE per workgroup
+  // (round 5): the scores then leave the MFMA in exp2 units and the per-element multiply before v_exp_f32 disappears.  One more
+  // rounding of q to the storage type (relative 2^-9 / 2^-11, random per element like the rounding q already carries from
+  // the qkv GEMM's epilogue); the exact 1/8 pre-scaling stays in the weights.
+  constexpr float LOG2E = 1.4426950408889634f;
   s16x8 qf[4];
   {
     const bf16_t* qp = base + (int64_t)min(q0 + r, Tn - 1) * ld + 8 * hf;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const s16x8*)(qp + 16 * ks);
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 t = *(const uint4*)(qp + 16 * ks);
+      float v[8];
+      up8<T16>(t, v);
+      t.x = N16<T16>::pk(v[0] * LOG2E, v[1] * LOG2E); t.y = N16<T16>::pk(v[2] * LOG2E, v[3] * LOG2E);
+      t.z = N16<T16>::pk(v[4] * LOG2E, v[5] * LOG2E); t.w = N16<T16>::pk(v[6] * LOG2E, v[7] * LOG2E);
+      qf[ks] = __builtin_bit_cast(s16x8, t);
+    }
   }
+  // a wave whose 32 queries all lie past the end of the sequence (the last q-block of T = 1500 carries 92 queries: wave 3 has
+  // none) stages its share of K / V and keeps the barriers, but runs no MFMA / softmax
+  const bool live = q0 < Tn;
 
-  // staging map: thread -> (row, chunk) x 2 for K and V
-  const int srow = tid >> 2, sc0 = (tid & 3) * 2;  // rows 0..63, chunks {sc0, sc0+1}
-  uint4 kreg0, kreg1, vreg0, vreg1;
-#define FA_G_LOAD(kt_)                                                      \
-  do {                                                                      \
-    const int key_ = min((kt_) * FA_KB + srow, n_k - 1);                    \
-    const bf16_t* kp_ = kbase + (int64_t)key_ * kld + sc0 * 8;              \
-    const bf16_t* vp_ = vbase + (int64_t)key_ * kld + sc0 * 8;              \
-    kreg0 = *(const uint4*)kp_; kreg1 = *(const uint4*)(kp_ + 8);           \
-    vreg0 = *(const uint4*)vp_; vreg1 = *(const uint4*)(vp_ + 8);           \
-  } while (0)
-  // K: chunk c of row k at c ^ ((k>>1)&7); V: 64-byte half (c >> 2) swapped by bit 1 of the row
-#define FA_S_STORE(buf_)                                                                                   \
-  do {                                                                                                     \
-    char* Kb_ = smem + (buf_) * 16384;                                                                     \
-    char* Vb_ = Kb_ + 8192;                                                                                \
-    const int sw_ = (srow >> 1) & 7;                                                                       \
-    *(uint4*)(Kb_ + srow * 128 + ((sc0 ^ sw_) << 4)) = kreg0;                                              \
-    *(uint4*)(Kb_ + srow * 128 + (((sc0 + 1) ^ sw_) << 4)) = kreg1;                                        \
-    *(uint4*)(Vb_ + srow * 128 + ((((sc0 >> 2) ^ (sw_ & 1)) << 6) | ((sc0 & 3) << 4))) = vreg0;            \
-    *(uint4*)(Vb_ + srow * 128 + (((((sc0 + 1) >> 2) ^ (sw_ & 1)) << 6) | (((sc0 + 1) & 3) << 4))) = vreg1; \
+  // K / V staging by LDS-DMA (round 5): a wave-instruction of global_load_lds moves 1 KiB = 8 rows x 128 B straight into the LDS
+  // image (no VGPR staging, no ds_write).  A tile is 8 K pieces + 8 V pieces; wave w issues K pieces 2w, 2w+1 and V pieces 2w,
+  // 2w+1.  Lane l of piece p lands in row 8p + l/8, 16-byte slot l%8, so it FETCHES the chunk that belongs in that slot under
+  // the image's swizzle (K: chunk c of row k sits in slot c ^ ((k>>1)&7); V: slot c ^ (((k>>1)&1) << 2)): source-side swizzle.
+  // The per-lane source offsets are loop constants (32 bit); the tile base advances on the scalar unit.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int prow = lane >> 3, pslot = lane & 7;
+  uint32_t koff[2], voff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int row = (2 * wave_u + p) * 8 + prow;
+    koff[p] = (uint32_t)(row * (int)kld + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2u;
+    voff[p] = (uint32_t)(row * (int)kld + ((pslot ^ (((row >> 1) & 1) << 2)) << 3)) * 2u;
+  }
+  const int64_t tstep = (int64_t)FA_KB * kld * 2;              // bytes per tile
+  const int full_tiles = n_k / FA_KB;                          // tiles 0 .. full_tiles-1 need no clamp
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef void __attribute__((address_space(3)))* lptr_t;
+#define FA_DMA(kt_, buf_)                                                                                          \
+  do {                                                                                                             \
+    char* Kb_ = smem + (buf_) * 16384 + (2 * wave_u) * 1024;                                                       \
+    char* Vb_ = Kb_ + 8192;                                                                                        \
+    if ((kt_) < full_tiles) {                                                                                      \
+      const char* kt_base_ = (const char*)kbase + (int64_t)(kt_) * tstep;                                          \
+      const char* vt_base_ = (const char*)vbase + (int64_t)(kt_) * tstep;                                          \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                              \
+        __builtin_amdgcn_global_load_lds((gptr_t)(kt_base_ + koff[p]), (lptr_t)(Kb_ + p * 1024), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((gptr_t)(vt_base_ + voff[p]), (lptr_t)(Vb_ + p * 1024), 16, 0, 0);        \
+      }                                                                                                            \
+    } else {                                                                                                       \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                                              \
+        const int row_ = (2 * wave_u + p) * 8 + prow;                                                              \
+        const int key_ = min((kt_) * FA_KB + row_, n_k - 1);                                                       \
+        const bf16_t* kp_ = kbase + (int64_t)key_ * kld + ((pslot ^ ((row_ >> 1) & 7)) << 3);                      \
+        const bf16_t* vp_ = vbase + (int64_t)key_ * kld + ((pslot ^ (((row_ >> 1) & 1) << 2)) << 3);               \
+        __builtin_amdgcn_global_load_lds((gptr_t)kp_, (lptr_t)(Kb_ + p * 1024), 16, 0, 0);                         \
+        __builtin_amdgcn_global_load_lds((gptr_t)vp_, (lptr_t)(Vb_ + p * 1024), 16, 0, 0);                         \
+      }                                                                                                            \
+    }                                                                                                              \
   } while (0)
 
   f32x16 o[2];
@@ -96,38 +128,47 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  constexpr float LOG2E = 1.4426950408889634f;
+  // Online softmax with the reference maximum INSIDE the score MFMA (round 5): the accumulator of S^T = K Q^T starts at -m_ref
+  // (sinit: 16 registers holding this lane's query's -m_ref), so the MFMA delivers s - m_ref and p = exp2(s - m_ref) costs one
+  // v_exp_f32 per element and nothing else.  m_ref follows the running maximum lazily (guide T13): it moves only when a tile's
+  // maximum exceeds it by more than FA_THR (in exp2 units: p <= 2^FA_THR = 64, well inside bf16 / fp16), and the first tile
+  // always sets it.  The decision is taken BEFORE the tile's P is exponentiated and scales o, l and this tile's scores exactly
+  // once (T13's hazard), so the result is the exact softmax whatever m_ref is; what changes against the running-maximum form is
+  // rounding only (the largest p of a row is no longer exactly 1).
+  constexpr float FA_THR = 6.0f;
+  f32x16 sinit;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sinit[j] = 0.f;
+  float m_ref = 0.f, l_run = 0.f;
 
   const int n_tiles = (n_k + FA_KB - 1) / FA_KB;
-  FA_G_LOAD(0);
-  FA_S_STORE(0);
-  __syncthreads();
+  FA_DMA(0, 0);
+  __syncthreads();   // s_waitcnt vmcnt(0) (every wave's own pieces landed) + barrier
 
   // per-lane constant parts of the LDS read addresses
   //   K fragment (kb2, ks): row = 32*kb2 + r, chunk = 2*ks + hf
   //   V tr-read (s, db, part): row = 16*s + 8*part + 4*hf + ((lane & 15) >> 2); byte = 64*db' + 32*((lane>>4)&1) + 8*(lane&3)
   const int vq = (lane & 15) >> 2, vp4 = lane & 3, vg = (lane >> 4) & 1;
 
-  auto tile = [&](const int kt, auto last_tag) {
+  // cur_tag: which LDS image this tile reads (compile-time: every LDS address is base + immediate); last_tag: the peeled last tile
+  auto tile = [&](const int kt, auto cur_tag, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;
-    const int cur = kt & 1;
-    if (!LAST) FA_G_LOAD(kt + 1);
+    constexpr int cur = decltype(cur_tag)::value;
+    // tile kt + 1 into the other image: its last readers (tile kt - 1) are behind the barrier every wave has passed
+    if (!LAST) FA_DMA(kt + 1, cur ^ 1);
     const char* Kb = smem + cur * 16384;
     const char* Vb = Kb + 8192;
-
-    // ---- S^T = K Q^T : two 32-key blocks ----
+    if (live) {
+    // ---- S^T - m_ref = K Q^T - m_ref : two 32-key blocks ----
     f32x16 s[2];
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s[kb2][j] = 0.f;
       const int krow = 32 * kb2 + r;
       const int ksw = (krow >> 1) & 7;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s16x8 kf = *(const s16x8*)(Kb + krow * 128 + (((2 * ks + hf) ^ ksw) << 4));
-        s[kb2] = N16<T16>::mfma32(kf, qf[ks], s[kb2]);
+        s[kb2] = N16<T16>::mfma32(kf, qf[ks], ks == 0 ? sinit : s[kb2]);
       }
     }
     if (LAST) {  // mask keys past the end of the sequence (only the peeled last tile carries this code)
@@ -139,37 +180,37 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
           if (key >= n_k) s[kb2][j] = -1e30f;
         }
     }
-    // ---- online softmax: this lane's query column ----
+    // ---- this lane's query column: how far above the reference is the tile's maximum? ----
     float tmax = s[0][0];
 #pragma unroll
     for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, s[0][j]);
 #pragma unroll
     for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, s[1][j]);
     tmax = xor32_reduce(tmax, OpMax{});  // v_permlane32_swap: no LDS round trip in the tile loop
-    const float m_new = fmaxf(m_run, tmax);
-    const float mb = -m_new * LOG2E;
-    float psum = 0.f;
-    uint32_t pf[2][8];  // bf16-packed P^T: [kb2][2*s' + pair]
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-      for (int j = 0; j < 16; j += 2) {
-        float p0 = __builtin_amdgcn_exp2f(fmaf(s[kb2][j], LOG2E, mb));
-        float p1 = __builtin_amdgcn_exp2f(fmaf(s[kb2][j + 1], LOG2E, mb));
-        psum += p0 + p1;
-        pf[kb2][j >> 1] = N16<T16>::pk(p0, p1);
-      }
-    // rescale the running sums only when some query of this wave saw a new maximum (exact: alpha == 1 otherwise);
-    // after the first few tiles this is rare, and it keeps 32 multiplies + an exp out of the steady-state loop
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const bool move = (kt == 0) | (tmax > FA_THR);
+    if (__builtin_amdgcn_ballot_w64(move) != 0) {   // rare after the first tile: move the reference of the queries that need it
+      const float delta = move ? tmax : 0.f;       // exp2(0) = 1 exactly for the others
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) o[i][j] *= alpha;
-      m_run = m_new;
+        for (int j = 0; j < 16; ++j) { o[i][j] *= alpha; s[i][j] -= delta; }
+      m_ref += delta;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sinit[j] = -m_ref;
     }
+    float psum = 0.f;
+    uint32_t pf[2][8];  // 16-bit-packed P^T: [kb2][2*s' + pair]
+#pragma unroll
+    for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[kb2][j]);
+        const float p1 = __builtin_amdgcn_exp2f(s[kb2][j + 1]);
+        psum += p0 + p1;
+        pf[kb2][j >> 1] = N16<T16>::pk(p0, p1);
+      }
     l_run += psum;
 
     // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 2 d-blocks ----
@@ -194,11 +235,22 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
         o[db] = N16<T16>::mfma32(vf, pb, o[db]);
       }
     }
-    if (!LAST) FA_S_STORE(cur ^ 1);
-    __syncthreads();
+    }  // live
+    __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 landed; barrier: everybody's did
   };
-  for (int kt = 0; kt + 1 < n_tiles; ++kt) tile(kt, std::false_type{});
-  tile(n_tiles - 1, std::true_type{});
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 2 < n_tiles; kt += 2) {
+    tile(kt, B0{}, std::false_type{});
+    tile(kt + 1, B1{}, std::false_type{});
+  }
+  if (kt + 2 == n_tiles) {
+    tile(kt, B0{}, std::false_type{});
+    tile(kt + 1, B1{}, std::true_type{});
+  } else {
+    tile(kt, B0{}, std::true_type{});
+  }
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B ----
   const float l_tot = xor32_reduce(l_run, OpSum{});

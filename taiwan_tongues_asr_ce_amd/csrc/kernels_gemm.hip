@@ -663,7 +663,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nwg = tiles_m * tiles_n;
+  const int tiles_per_group = tiles_m * tiles_n;
+  const int nwg = tiles_per_group * g.groups;
   // static schedule: the workgroups that share an XCD (bid % 8) own one contiguous range of tiles and walk it round-robin
   const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this class
   const int q = nwg >> 3, r = nwg & 7;
@@ -681,9 +682,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
   constexpr int GM = 4;
 
   int m0 = 0, n0 = 0;
+  int64_t oofs = 0;          // output offset of the tile's group (elements)
+  const float* bias_g = e.bias;
   const bf16_t* a_src[2];
   const bf16_t* w_src[2];
-  auto place = [&](int tile) {   // tile -> (m0, n0), staging source pointers (same raster as v3)
+  auto place = [&](int tile) {   // tile -> (group,) (m0, n0), staging source pointers (same raster as v3 inside a group)
+    const bf16_t* Wg = W;
+    if (g.groups > 1) {
+      const int grp = tile / tiles_per_group;
+      tile -= grp * tiles_per_group;
+      Wg = W + (int64_t)grp * g.group_stride_w;
+      bias_g = e.bias + (int64_t)grp * g.N;
+      oofs = (int64_t)grp * g.group_stride_out;
+    }
     const int band = tile / (GM * tiles_n);
     const int rows_in_band = min(GM, tiles_m - band * GM);
     const int in_band = tile - band * GM * tiles_n;
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
       const int row = (wave * 2 + p) * 16 + srow;
       const int chunk = sslot ^ v3_h((row >> 2) & 3);
       a_src[p] = A + (int64_t)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
-      w_src[p] = W + (int64_t)(n0 + row) * g.ldw + chunk * 8;
+      w_src[p] = Wg + (int64_t)(n0 + row) * g.ldw + chunk * 8;
     }
   };
 #define V4_STAGE(slot_, k0_)                                                                   \
@@ -708,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
   } while (0)
   auto load_bias = [&](float4 (&b4)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b4[j] = *(const float4*)(e.bias + n0 + wn * 64 + fq * 4 + j * 16);   // bias != nullptr (gemm_bf16_v4_ok)
+    for (int j = 0; j < 4; ++j) b4[j] = *(const float4*)(bias_g + n0 + wn * 64 + fq * 4 + j * 16);   // bias != nullptr (gemm_bf16_v4_ok)
     // waited for HERE, while nothing else is in flight: no later use of these registers may drain the LDS-DMA queue
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(b4[0].x), "+v"(b4[0].y), "+v"(b4[0].z), "+v"(b4[0].w), "+v"(b4[1].x), "+v"(b4[1].y),
                  "+v"(b4[1].z), "+v"(b4[1].w), "+v"(b4[2].x), "+v"(b4[2].y), "+v"(b4[2].z), "+v"(b4[2].w), "+v"(b4[3].x),
@@ -772,8 +783,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
       const int n = nbase + j * 16;
       if (HS) {
         const int which = n / e.hs_d, nn = n - which * e.hs_d;
-        coloff[j] = (int64_t)which * e.hs_which + (int64_t)(nn >> 6) * e.hs_T * 64 + (nn & 63);
-      } else coloff[j] = n;
+        coloff[j] = oofs + (int64_t)which * e.hs_which + (int64_t)(nn >> 6) * e.hs_T * 64 + (nn & 63);
+      } else coloff[j] = oofs + n;
     }
     const int mrow0 = m0 + wm * 128 + fr;
     // ---- next tile: bias (waited for now), then its first three stages into the free ring ----
@@ -830,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
 
 bool gemm_bf16_v4_ok(const GemmArgs& g) {
   const int code = v3_epi_code(g.epi);
-  return (code == 0 || code == 1 || code == 8) && g.batch <= 1 && g.epi.bias != nullptr && gemm_bf16_v3_ok(g);
+  return (code == 0 || code == 1 || code == 8) && g.batch <= 1 && g.groups >= 1 && g.epi.bias != nullptr && gemm_bf16_v3_ok(g);
 }
 // Per-device launcher state, set ONCE per device by gemm_tiles_init (ttasr_create calls it before the context can launch
 // anything; std::call_once orders the writes before every later reader): the opt-in to > 64 KiB of dynamic LDS for every tiled
@@ -860,8 +871,8 @@ template <typename T16, int EPI>
 static void launch_v4(const GemmArgs& g, hipStream_t s) {
   int dev = 0;
   hipGetDevice(&dev);
-  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
-  const int grid = std::min(tiles_m * tiles_n, g_v4_cus[dev & 63]);
+  const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;   // per group
+  const int grid = std::min(tiles_m * tiles_n * std::max(1, g.groups), g_v4_cus[dev & 63]);
   if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "gemm_bf16_v4_kernel<%s, %d> grid %d", sig_type<T16>(), EPI, grid * 512);
   hipLaunchKernelGGL((gemm_bf16_v4_kernel<T16, EPI>), dim3(grid), dim3(512), 4 * 32768, s, g, tiles_m, tiles_n);
 }

@@ -100,3 +100,54 @@ def test_flash_attention_matches_the_plain_attention_kernel_at_ragged_windows():
         assert np.isfinite(a).all()
         err = np.abs(a - b)
         assert err.max() < 0.05 and err.mean() < 0.004, (n_ctx, float(err.max()), float(err.mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute", ["bf16", "f16"])
+def test_flash_attention_with_a_wide_score_range(compute):
+    """Round 5: the flash kernel keeps its softmax reference INSIDE the score MFMA (the accumulator starts at -m_ref) and moves
+    it lazily - only when a tile's maximum exceeds it by more than 6 exp2 units (kernels_flash.hip).  With LayerNorm-scale
+    activations the reference moves in the first tiles and then rarely, so this test MAKES the scores wide: the query
+    projections of both encoder layers are scaled x 6 (scores spread over several dozen exp2 units; the reference of most rows
+    moves many times, o / l / the tile's scores are rescaled each time), at Whisper's window, at a window that ends inside a key
+    tile and at a single partial tile.  Graded against the plain attention
+    kernel (option `flash = 0`: one query per wave, exact two-pass softmax) on the same 16-bit q / k / v, and against the f32
+    oracle holding the same rounded weights."""
+    from taiwan_tongues_asr_ce_amd.config import COMPUTE_F16
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    ct = COMPUTE_F16 if compute == "f16" else COMPUTE_BF16
+    dims = PRESETS["large-v3-w2"]
+    rd = R.Dims(**dims.as_dict())
+    sd = dict(synth.state_dict(dims))
+    for layer in (0, 1):
+        for suffix in (".weight", ".bias"):
+            k = f"model.encoder.layers.{layer}.self_attn.q_proj{suffix}"
+            sd[k] = (sd[k] * np.float32(6.0)).astype(np.float32)
+    clips = [synth.tonal_clip(0), synth.noise_clip(1), synth.burst_clip(2)]
+    windows = (0, 150, 20)
+    outs = {}
+    for plain in (False, True):
+        e = Engine(dims, ct, 3)
+        e.set_option("flash", 0 if plain else 1)
+        e.load_weights(sd.items())
+        for n_ctx in windows:
+            e.set_audio_ctx(n_ctx)
+            e.log_mel(clips, want_output=False)
+            outs[plain, n_ctx] = e.encode(3, want_output=True).copy()
+        e.close()
+    # measured: bf16 0.039 max / 0.0045 mean at the 30-s window (sharper softmax rows than the unscaled test above: 0.05 / 0.004
+    # there), fp16 a quarter of that
+    tol_max, tol_mean = (0.06, 0.006) if compute == "bf16" else (0.02, 0.0015)
+    for n_ctx in windows:
+        a, b = outs[False, n_ctx], outs[True, n_ctx]
+        assert np.isfinite(a).all()
+        err = np.abs(a - b)
+        assert err.max() < tol_max and err.mean() < tol_mean, (compute, n_ctx, float(err.max()), float(err.mean()))
+    # and the oracle (f32 arithmetic on the same rounded weights) at the full window: the bf16 / fp16 encoder tolerances of this file
+    W = R.to_torch(sd, round_bf16=compute == "bf16", round_f16=compute == "f16")
+    from oracle_checks import encode_chunked
+    mel_ref = np.stack([R.log_mel(c, dims.n_mels) for c in clips])
+    enc_ref = encode_chunked(mel_ref, W, rd).numpy()
+    err = np.abs(outs[False, 0] - enc_ref)
+    lim = (0.15, 0.012) if compute == "bf16" else (0.04, 0.004)
+    assert err.max() < lim[0] and err.mean() < lim[1], (compute, float(err.max()), float(err.mean()))

@@ -464,15 +464,19 @@ def test_round4_options_are_bit_identical_to_their_off_form():
     for n_ctx, cl in ((0, clips), (150, short), (46, short)):     # Whisper's window; the streaming path's 3-s window; a ragged one
         e.set_audio_ctx(n_ctx)                                    # (46 frames: the last batch of the pipelined stream is partial)
         ref = None
-        for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0}):
-            for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, **key_vals}.items():
+        # round 5: `xkv_grouped` - the cross-KV projections of all decoder layers as ONE grouped launch of the persistent GEMM
+        # (at the 30-s window: 2 layers x 940 tiles; the short windows have too few tiles and take the per-layer launches anyway)
+        for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xkv_grouped": 0},
+                         {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0, "xkv_grouped": 0}):
+            for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, "xkv_grouped": 1, **key_vals}.items():
                 e.set_option(k, v)
             e.log_mel(cl, want_output=False)
             enc = e.encode(16, want_output=True)
+            xkv = [e.cross_kv(layer, which, 16).copy() for layer in (0, 1) for which in (0, 1)] if n_ctx != 46 else []
             e.decode_reset(16)
             lg = [e.decode_step([t] * 16).copy() for t in prompt]
             r = e.generate([prompt] * 16, e.gen_opts(12, False, suppress_eot=True))
-            cur = (enc, lg, r.tokens, r.sum_logprob.copy())
+            cur = (enc, lg + xkv, r.tokens, r.sum_logprob.copy())
             if ref is None:
                 ref = cur
             else:

@@ -4,32 +4,44 @@
 #   the kernels it launches), and the side lines (fp16, fp8 cross-KV, other geometries).  Everything lands under gpurun_out/session/.
 set -x
 cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 O=$GRAFT_REPO_ROOT/gpurun_out/session; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
-timeout 600 python bench.py --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400 $O/bench.json; echo
+timeout 900 python bench.py --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400 $O/bench.json; echo
 cp profiles/bench_tokens_crc.json $O/
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
+# the profiled command = the headline configuration only (--no-side: the side modes launch the same kernels from two contexts at
+# once and in fp16 / fp8 forms, which would mix regimes in one per-kernel average; --no-cpu-baseline: host time only)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-side --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
 f=$(find $O/prof -name '*kernel_stats.csv' | head -1); cp $f $O/kernel_stats.csv; head -3 $O/kernel_stats.csv | cut -c1-250; rm -rf $O/prof
 for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
   tag=$(echo $p | cut -d' ' -f1)
-  timeout 900 rocprofv3 --pmc $p --output-format csv -d $O/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; echo "pmc $tag rc=$?"
+  timeout 900 rocprofv3 --pmc $p --output-format csv -d $O/pmc_$tag -- python3 bench.py --steps 1 --warmup 0 --new-tokens 8 --no-side --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err; rc=$?; echo "pmc $tag rc=$rc"
+  [ $rc -eq 0 ] || PMC_FAILED=1
 done
 python tools/microbench/pmc_report.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES $TAG $O > $O/pmc_report.txt 2>&1; tail -3 $O/pmc_report.txt
 find $O -name "*counter_collection.csv" -delete; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ_VALU_MFMA_BUSY_CYCLES
 # with the refreshed profiles in place: the line the judge will see (traffic / pmc_mfma_busy_frac quoted, signatures match)
-cp $O/xattn_pmc.json profiles/xattn_pmc.json; cp $O/${TAG}_pmc.json profiles/${TAG}_pmc.json
+# ... but only when all three counter passes returned 0 and the aggregated JSON really holds kernels with signatures: a failed or
+# timed-out pass must not replace the good committed profile with an empty one
+if [ -z "$PMC_FAILED" ] && python - $O/xattn_pmc.json $O/${TAG}_pmc.json <<'PY'
+import json, sys
+x = json.load(open(sys.argv[1])); p = json.load(open(sys.argv[2]))
+ok = bool(x.get("signatures")) and x.get("traffic_bytes_per_32row_launch", 0) > 0 and bool(p.get("kernels")) and \
+     all(v.get("signatures") for v in p["kernels"].values())
+sys.exit(0 if ok else 1)
+PY
+then cp $O/xattn_pmc.json profiles/xattn_pmc.json; cp $O/${TAG}_pmc.json profiles/${TAG}_pmc.json; echo "PMC profiles refreshed"
+else echo "PMC passes incomplete: profiles/ left untouched"; fi
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench final rc=$?"; head -c 300 $O/bench_final.json; echo
 # side lines (never the headline)
-timeout 400 python bench.py --compute f16 --write-crc --no-cpu-baseline > $O/bench_f16.json 2>/dev/null; echo "f16 rc=$?"
-timeout 400 python bench.py --xkv-fp8 --write-crc --no-cpu-baseline > $O/bench_xkv_fp8.json 2>/dev/null; echo "fp8 rc=$?"
-timeout 400 python bench.py --model large-v3-turbo --batch 32 --no-cpu-baseline > $O/bench_turbo_b32.json 2>/dev/null; echo "turbo rc=$?"
-timeout 400 python bench.py --model small --batch 8 --no-cpu-baseline > $O/bench_small_b8.json 2>/dev/null; echo "small rc=$?"
-timeout 400 python bench.py --new-tokens 444 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_444tok.json 2>/dev/null; echo "444 rc=$?"
-timeout 400 python bench.py --more-in-flight --no-cpu-baseline > $O/bench_more_in_flight.json 2>/dev/null; echo "mif rc=$?"
-timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$?"; head -c 300 $O/bench_gpus2_gloo.json; tail -2 $O/bench_gpus2.err
+timeout 400 python bench.py --compute f16 --write-crc --no-side --no-cpu-baseline > $O/bench_f16.json 2>/dev/null; echo "f16 rc=$?"
+timeout 400 python bench.py --xkv-fp8 --write-crc --no-side --no-cpu-baseline > $O/bench_xkv_fp8.json 2>/dev/null; echo "fp8 rc=$?"
+timeout 400 python bench.py --model large-v3-turbo --batch 32 --no-side --no-cpu-baseline > $O/bench_turbo_b32.json 2>/dev/null; echo "turbo rc=$?"
+timeout 400 python bench.py --model small --batch 8 --no-side --no-cpu-baseline > $O/bench_small_b8.json 2>/dev/null; echo "small rc=$?"
+timeout 400 python bench.py --new-tokens 444 --steps 3 --warmup 1 --no-side --no-cpu-baseline > $O/bench_444tok.json 2>/dev/null; echo "444 rc=$?"
+timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --no-side --no-cpu-baseline > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$?"; head -c 300 $O/bench_gpus2_gloo.json; tail -2 $O/bench_gpus2.err
 timeout 400 python tools/gemm_ab.py --rounds 3 > $O/gemm_persistent.jsonl 2>/dev/null; echo "gemm_ab rc=$?"
 timeout 400 python tools/stream_bench.py --model large-v3 --streams 8 --rounds 6 --beam 5 --max-clips 8 > $O/streaming.jsonl 2>/dev/null; echo "stream rc=$?"; tail -1 $O/streaming.jsonl | cut -c1-300
 timeout 400 python tools/stream_bench.py --model large-v3 --streams 8 --rounds 6 --beam 5 --max-clips 8 --audio-ctx auto >> $O/streaming.jsonl 2>/dev/null; tail -1 $O/streaming.jsonl | cut -c1-300
