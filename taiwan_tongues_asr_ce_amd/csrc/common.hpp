@@ -242,7 +242,9 @@ struct QProj {
 };
 
 // decode-time weight-streaming GEMM over MFMA-fragment-packed weights (kernels_skinny.hip)
-template <typename T16> void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s);
+template <typename T16> void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s, int rows_total = 0);
+int skinny_rows_per_block(int N, int K);   // 32 or 20 output rows per n-block of a packed decode matrix (kernels_skinny.hip)
+extern thread_local int g_skinny_narrow;    // option dec_narrow_blocks (set per C-ABI call from the context, like g_skinny_nt)
 // ksplit > 1 (from gemm_skinny_ksplit): workgroup (nb, ks) writes its partial tile to slab[ks]; bias is the consumer's
 template <typename T16>
 bool launch_gemm_skinny(const T16* Wsh, const T16* x, int B, int N, int K, const GemmEpi& e, hipStream_t s, int ksplit = 1,

@@ -16,7 +16,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
-  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; }   // this context's kernel variants for everything f launches
+  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; }   // this context's kernel variants for everything f launches
   g_launch_fault[0] = 0;
   try {
     const int rc = f();
@@ -187,9 +187,15 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
   }
   hipEventRecord(c->ev[0], s);
   if (!on_device) {
-    for (int b = 0; b < B; ++b)
-      if (ns[b] > 0)
-        HIPCHK(c, hipMemcpyAsync(c->pcm_dev + (int64_t)b * c->n_samples, pcm + b * pcm_stride, ns[b] * 4, hipMemcpyHostToDevice, s));
+    bool whole = pcm_stride == c->n_samples;   // full windows back to back (the batch path): ONE copy instead of B
+    for (int b = 0; b < B && whole; ++b) whole = ns[b] == c->n_samples;
+    if (whole) {
+      HIPCHK(c, hipMemcpyAsync(c->pcm_dev, pcm, (size_t)B * c->n_samples * 4, hipMemcpyHostToDevice, s));
+    } else {
+      for (int b = 0; b < B; ++b)
+        if (ns[b] > 0)
+          HIPCHK(c, hipMemcpyAsync(c->pcm_dev + (int64_t)b * c->n_samples, pcm + b * pcm_stride, ns[b] * 4, hipMemcpyHostToDevice, s));
+    }
     src = c->pcm_dev; stride = c->n_samples;
   }
   HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));

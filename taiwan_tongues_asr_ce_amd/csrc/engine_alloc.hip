@@ -129,7 +129,7 @@ int build_weights(ttasr_ctx* c) {
     auto packed = [&](const std::string& name, void** base, int64_t rows_total, int64_t K, int row_off) -> int {
       if (!*base) TRY(alloc_mat(c, base, (rows_total + 31) / 32 * 32 * K));
       Slot& s = c->slots[name];
-      s.sh_base = *base; s.sh_row_off = row_off;
+      s.sh_base = *base; s.sh_row_off = row_off; s.sh_rows_total = (int)rows_total;
       return 0;
     };
     TRY(packed("model.decoder.embed_tokens.weight", &c->emb_sh, V, d, 0));
@@ -246,10 +246,10 @@ int ingest_tensor(ttasr_ctx* c, const char* name, const void* src, int src_type,
   if (!to_f32) {
     if (c->f16) {
       launch_cast<f16_t>(c->stage_f32, (f16_t*)s.dst, n, c->stream);
-      if (s.sh_base) launch_shuffle_cast<f16_t>(c->stage_f32, (f16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
+      if (s.sh_base) { launch_shuffle_cast<f16_t>(c->stage_f32, (f16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream, s.sh_rows_total); c->weights_packed = true; }
     } else {
       launch_cast<bf16_t>(c->stage_f32, (bf16_t*)s.dst, n, c->stream);
-      if (s.sh_base) launch_shuffle_cast<bf16_t>(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream);
+      if (s.sh_base) { launch_shuffle_cast<bf16_t>(c->stage_f32, (bf16_t*)s.sh_base, (int)s.rows, (int)s.cols, s.sh_row_off, c->stream, s.sh_rows_total); c->weights_packed = true; }
     }
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffers are reused by the next tensor

@@ -33,6 +33,7 @@ struct Slot {              // where one named tensor lands on the device
   bool loaded = false;
   void* sh_base = nullptr;  // bf16 mode, decoder matrices: fragment-packed copy for the skinny GEMM
   int sh_row_off = 0;
+  int sh_rows_total = 0;    // rows of the whole packed matrix (a fused q/k/v matrix is packed as three parts): decides the block height
 };
 
 struct EncLayerW { float *ln1g, *ln1b, *bqkv, *bo, *ln2g, *ln2b, *b1, *b2; void *wqkv, *wo, *w1, *w2; };
@@ -116,6 +117,8 @@ struct ttasr_ctx {
   int B_mel = 0, B_enc = 0, B_dec = 0;
   std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one call in flight per context: a second concurrent call is refused
   int xattn_nt = 1, xattn_pipe = 1, weights_nt = 1;  // options xattn_nontemporal / xattn_pipeline / weights_nontemporal (per context; copied into the launchers' thread-locals by guarded())
+  bool dec_narrow = true;   // option dec_narrow_blocks: 20-row n-blocks for the decode matrices whose 32-row block count does not fill the 256 CUs evenly (fixed once weights are packed)
+  bool weights_packed = false;
   bool xkv_grouped = true;  // option xkv_grouped = 0: one cross-KV GEMM launch per decoder layer instead of one grouped launch (A/B testing; bit-identical)
   bool multi_step = true;   // option multi_step_graph = 0: one graph replay per decode step (A/B testing)
   bool no_xsplit = false;   // option xsplit = 0: never split the cross-attention frames over workgroups (A/B testing)

@@ -194,7 +194,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
     // out-proj at d = 1280 with one 32-row group: 5 slices (200 workgroups x 4 k-steps per wave) instead of the automatic 4 (160 x 5)
     // measured 2.8438 vs 2.8494 ms per decode step in two interleaved rounds (round 5; `tools/decode_variants.py
     // --variants auto,d5`): kept.  The q GEMM stays at 4: the attention consumers sum at most 4 slabs.
-    if (kind == 0 && want == 0 && n <= 32 && K == 1280 && N == 1280) want = 5;
+    if (kind == 0 && want == 0 && n <= 32 && K == 1280 && N == 1280 && skinny_rows_per_block(N, K) == 32) want = 5;
     int ks = gemm_skinny_ksplit(n, N, K, want);
     if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
     return ks;

@@ -29,36 +29,55 @@
 #include <cstdlib>
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+// Rows per n-block of a fragment-packed decode matrix (round 5).  The MFMA tile has 32 output rows, but a workgroup need not
+// use all of them: with 20-row blocks fc1 of the large-v3 family (N 5120, never K-split: GELU needs the full sum) runs as 256
+// workgroups of 51 KB of weights - one per CU - instead of 160 of 80 KB.  The packed stream holds ONLY the 20 rows (640 B per
+// k-step, contiguous); lanes 20..31 of each half re-read row 19 (same cache lines, no traffic) and their output rows are never
+// stored.  Measured per launch in a graph-replayed chain of cold matrices (tools/microbench/skinny_bench3.hip, round 5):
+//   fc1 7.83 -> 7.53 us;  fc2 (8 K slices) 7.27 -> 7.26;  out-proj / q 3.45 (32 rows, 5 slices) vs 3.77 (20 rows, 4 slices).
+// So only fc1 takes the narrow blocks (rule: the 20-row block count is a multiple of the 256 CUs); what these kernels wait for is
+// not the per-CU share of the stream alone - they sit 1.3-1.7 us above a kernel that only moves the same bytes on the same grid.
+thread_local int g_skinny_narrow = 1;   // option dec_narrow_blocks (per context; fixed once the weights are packed)
+int skinny_rows_per_block(int N, int K) {
+  (void)K;
+  if (!g_skinny_narrow) return 32;
+  return (N % 20 == 0 && (N / 20) % 256 == 0) ? 20 : 32;
+}
+
 template <typename T16>
-__global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int row_offset) {
-  // one thread per 16-byte output chunk; rows past `rows` (padding of the last 32-row block) are left zero
-  const int ks_per = K / 16;
-  const int n_blocks = (rows + 31) / 32;
-  const int64_t n_chunks = (int64_t)n_blocks * ks_per * 64;
+__global__ void shuffle_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int rows, int K, int row_offset, int rpb) {
+  // one thread per 16-byte output chunk; rows past `rows` (padding of the last block) are left zero.  Chunk order inside
+  // (n-block, k-step): [half = which 8 of the 16 inputs][row in block] - for rpb = 32 exactly lane order of the A operand
+  const int ks_per = K / 16, per = 2 * rpb;
+  const int n_blocks = (rows + rpb - 1) / rpb;
+  const int64_t n_chunks = (int64_t)n_blocks * ks_per * per;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(c & 63);
-    const int64_t blk = c >> 6;
+    const int within = (int)(c % per);
+    const int64_t blk = c / per;
     const int ks = (int)(blk % ks_per), nb = (int)(blk / ks_per);
-    const int r = nb * 32 + (lane & 31);
+    const int half = within / rpb, lr = within - half * rpb;
+    const int r = nb * rpb + lr;
     if (r >= rows) continue;
-    const float* s = src + (int64_t)r * K + ks * 16 + 8 * (lane >> 5);
+    const float* s = src + (int64_t)r * K + ks * 16 + 8 * half;
     uint4 o;
     o.x = N16<T16>::pk(s[0], s[1]);
     o.y = N16<T16>::pk(s[2], s[3]);
     o.z = N16<T16>::pk(s[4], s[5]);
     o.w = N16<T16>::pk(s[6], s[7]);
-    ((uint4*)dst)[((int64_t)(nb + row_offset / 32) * ks_per + ks) * 64 + lane] = o;
+    ((uint4*)dst)[((int64_t)(nb + row_offset / rpb) * ks_per + ks) * per + within] = o;
   }
 }
+// rows_total = rows of the whole packed matrix (a fused q/k/v matrix arrives as three parts): it decides the block height
 template <typename T16>
-void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s) {
-  const int64_t n_chunks = (int64_t)((rows + 31) / 32) * (K / 16) * 64;
+void launch_shuffle_cast(const float* src, T16* dst_base, int rows, int K, int row_offset, hipStream_t s, int rows_total) {
+  const int rpb = skinny_rows_per_block(rows_total > 0 ? rows_total : rows, K);
+  const int64_t n_chunks = (int64_t)((rows + rpb - 1) / rpb) * (K / 16) * 2 * rpb;
   const int64_t nb = (n_chunks + 255) / 256;
   hipLaunchKernelGGL(shuffle_cast_kernel<T16>, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, (bf16_t*)dst_base, rows, K,
-                     row_offset);
+                     row_offset, rpb);
 }
-template void launch_shuffle_cast<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t);
-template void launch_shuffle_cast<f16_t>(const float*, f16_t*, int, int, int, hipStream_t);
+template void launch_shuffle_cast<bf16_t>(const float*, bf16_t*, int, int, int, hipStream_t, int);
+template void launch_shuffle_cast<f16_t>(const float*, f16_t*, int, int, int, hipStream_t, int);
 
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
@@ -71,13 +90,14 @@ thread_local int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEM
 template <typename T16, int NW, int RB, int U, bool NT, bool ONE>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __restrict__ Wsh_, const bf16_t* __restrict__ x_,
                                                               int B_, int N_, int K_, int ksplit_, int steps_, GemmEpi e,
-                                                              float* __restrict__ slab_, int64_t slab_stride_) {
+                                                              float* __restrict__ slab_, int64_t slab_stride_, int rpb_) {
   // U = k-steps in flight per wave (register budget: U * (1 + RB) * 4); the launcher picks the smallest instantiated
   // U >= steps so that no load is issued twice
   __shared__ __attribute__((aligned(16))) float red[NW][RB][32 * 32];  // [wave][row group][b*32 + n]
   const bf16_t* Wsh = sgpr_pin_ptr(Wsh_);
   const bf16_t* x = sgpr_pin_ptr(x_);
   const int B = sgpr_pin(B_), N = sgpr_pin(N_), K = sgpr_pin(K_), ksplit = sgpr_pin(ksplit_);
+  const int rpb = sgpr_pin(rpb_);      // rows per n-block of the packed matrix (32 or 20: skinny_rows_per_block)
   const int steps = sgpr_pin(steps_);  // k-steps per wave = K / 16 / (NW * ksplit), divided on the host: an integer division here is
                                        // ~40 dependent instructions in front of the first load
   float* slab = sgpr_pin_ptr(slab_);
@@ -88,18 +108,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   const int nb = blockIdx.x, ks = blockIdx.y;
   const int ks_per = K / 16;
   const int k0 = (ks * NW + wave) * steps;
-  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * ks_per + k0) * 64 + lane;
+  // 16-byte chunk of lane `lane` in (n-block, k-step): [half][row]; lanes past the block's rows re-read its last row
+  const int wstep = 2 * rpb;
+  const u32x4* wp = (const u32x4*)Wsh + ((int64_t)nb * ks_per + k0) * wstep + (lane >> 5) * rpb + min(lane & 31, rpb - 1);
   const bf16_t* xp[RB];
 #pragma unroll
   for (int g = 0; g < RB; ++g) xp[g] = x + (int64_t)min(g * 32 + (lane & 31), B - 1) * K + k0 * 16 + 8 * (lane >> 5);
-  const int en = nb * 32 + 4 * (tid & 7);
+  const int en = nb * rpb + 4 * (tid & 7);
+  const bool ecell = tid < 256 && 4 * (tid & 7) < rpb;   // this thread owns 4 output columns of the block
   float4 ebias = make_float4(0.f, 0.f, 0.f, 0.f), eres[RB];
 #pragma unroll
   for (int g = 0; g < RB; ++g) eres[g] = ebias;
   // epilogue operands of this thread's 4 cells per row group (b = 32g + tid>>3, n = nb*32 + 4*(tid&7) ..+3): requested
   // together with the fragments (after them: the weights are the long pole)
   auto prefetch_epilogue = [&]() {
-    if (tid < 256 && en + 3 < N) {
+    if (ecell && en + 3 < N) {
       if (e.bias && ksplit == 1) ebias = *(const float4*)(e.bias + en);
       if (e.residual && ksplit == 1) {
 #pragma unroll
@@ -117,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = min(u, steps - 1);  // clamped and unconditional: nothing branches around a load
-      if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64); else w[u] = wp[(int64_t)i * 64];
+      if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * wstep); else w[u] = wp[(int64_t)i * wstep];
 #pragma unroll
       for (int g = 0; g < RB; ++g) xv[g][u] = *(const u32x4*)(xp[g] + i * 16);
     }
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = min(i0 + u, steps - 1);
-        if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * 64); else w[u] = wp[(int64_t)i * 64];
+        if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * wstep); else w[u] = wp[(int64_t)i * wstep];
 #pragma unroll
         for (int g = 0; g < RB; ++g) xv[g][u] = *(const u32x4*)(xp[g] + i * 16);
       }
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
       *(float4*)&red[wave][g][(lane & 31) * 32 + 8 * q + 4 * (lane >> 5)] =
           make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
   __syncthreads();
-  if (tid >= 256) return;
+  if (!ecell) return;
 #pragma unroll
   for (int g = 0; g < RB; ++g) {
     float4 v = *(const float4*)&red[0][g][(tid >> 3) * 32 + 4 * (tid & 7)];
@@ -349,7 +372,8 @@ template bool launch_gemm_vocab<f16_t>(const f16_t*, const f16_t*, int, int, int
 // pieces of <= ~20 KB per workgroup, a few hundred workgroups); the result divides the k-steps evenly over 4 waves.
 int gemm_skinny_ksplit(int B, int N, int K, int want) {
   if (B < 1 || B > 128 || K % 64 != 0) return 1;
-  const int rb = (B + 31) / 32, n_blocks = (N + 31) / 32, ks_per = K / 16;
+  const int rpb = skinny_rows_per_block(N, K);
+  const int rb = (B + 31) / 32, n_blocks = (N + rpb - 1) / rpb, ks_per = K / 16;
   const int per4 = ks_per / 4;  // k-steps per wave of a 4-wave workgroup when unsplit
   if (ks_per % 4 != 0) return 1;
   int best = 1;
@@ -378,7 +402,8 @@ bool launch_gemm_skinny(const T16* Wsh_, const T16* x_, int B, int N, int K, con
   const bf16_t* x = (const bf16_t*)x_;
   if (B < 1 || B > 128 || K % 64 != 0 || e.rowtab || e.headsplit) return false;
   const int rb = (B + 31) / 32;  // 32-row groups sharing one weight stream
-  const int n_blocks = (N + 31) / 32;
+  const int rpb = skinny_rows_per_block(N, K);
+  const int n_blocks = (N + rpb - 1) / rpb;
   const int ks_per = K / 16;
   const int u_max = rb == 1 ? 10 : (rb == 2 ? 8 : 5);  // k-steps a wave can keep in flight (registers)
   int nw = 4;
@@ -395,8 +420,8 @@ bool launch_gemm_skinny(const T16* Wsh_, const T16* x_, int B, int N, int K, con
   dim3 grid(n_blocks, ksplit);
 #define TTASR_SKINNY(NW_, RB_, U_, ONE_)                                                                                              \
   do {                                                                                                                                \
-    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
-    else hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride); \
+    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpb); \
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpb); \
   } while (0)
 #define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
   do {                                                                             \

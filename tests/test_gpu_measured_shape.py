@@ -174,3 +174,40 @@ def test_whole_measured_decode_length_against_the_oracle(world, compute, tol, ma
             again = e.generate([prompt] * B, opts)
             assert again.tokens == res.tokens and np.array_equal(again.sum_logprob, res.sum_logprob)
     e.close()
+
+
+def test_decode_weight_layouts_20_and_32_row_blocks_agree_with_the_oracle(world):
+    """Round 5: at ffn = 5120 the fragment-packed fc1 matrix of the decode step uses 20-row n-blocks (256 workgroups, one per CU,
+    instead of 160; option `dec_narrow_blocks`, default 1); every other matrix keeps 32-row blocks.  Both layouts - the default
+    and the classic one - are held to the oracle on 8 rows of a B = 32 batch: step logits of the prompt positions + two text
+    positions within 0.08 (bf16-rounded weights).  fc1 is never K-split, so the two layouts compute every value in the same
+    order: logits and greedy tokens are IDENTICAL bit for bit."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine, TtasrError
+    sd, clips, mel_ref = world
+    rd = R.Dims(**DIMS.as_dict())
+    Wb = R.to_torch(sd, round_bf16=True)
+    rows = list(range(0, 32, 4))
+    enc_ref = encode_chunked(np.stack([mel_ref[r] for r in rows]), Wb, rd)
+    xkv = R.cross_kv(enc_ref, Wb, rd)
+    toks = {}
+    for narrow in (1, 0):
+        e = Engine(DIMS, COMPUTE_BF16, BMAX)
+        e.set_option("dec_narrow_blocks", narrow)
+        e.load_weights(sd.items())
+        with pytest.raises(TtasrError):                      # a layout choice: refused once the weights are packed
+            e.set_option("dec_narrow_blocks", 1 - narrow)
+        st = e.special
+        prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+        e.log_mel(clips[:BMAX], want_output=False)
+        e.encode(BMAX)
+        e.decode_reset(BMAX)
+        cache = R.SelfCache.empty(rd.dec_layers)
+        for t in prompt + [1234, 777]:
+            lg = e.decode_step([t] * BMAX)[rows]
+            want = R.decoder_forward(torch.full((len(rows), 1), t), cache, xkv, Wb, rd)[:, 0].numpy()
+            err = np.abs(lg - want).max(axis=1)
+            assert err.max() < 0.08, (narrow, t, float(err.max()))
+        r = e.generate([prompt] * BMAX, e.gen_opts(16, False, suppress_eot=True))
+        toks[narrow] = (r.tokens, r.sum_logprob.copy(), lg.copy())
+        e.close()
+    assert toks[0][0] == toks[1][0] and np.array_equal(toks[0][1], toks[1][1]) and np.array_equal(toks[0][2], toks[1][2])

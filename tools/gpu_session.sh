@@ -9,8 +9,8 @@ O=$GRAFT_REPO_ROOT/gpurun_out/session; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
-timeout 900 python bench.py --write-crc > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400 $O/bench.json; echo
-cp profiles/bench_tokens_crc.json $O/
+timeout 900 python bench.py --write-crc --dump-tokens $O/bench_tokens_bf16.npy > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400 $O/bench.json; echo
+cp profiles/bench_tokens_crc.json $O/; cp $O/bench_tokens_bf16.npy profiles/bench_tokens_bf16.npy
 # the profiled command = the headline configuration only (--no-side: the side modes launch the same kernels from two contexts at
 # once and in fp16 / fp8 forms, which would mix regimes in one per-kernel average; --no-cpu-baseline: host time only)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-side --no-cpu-baseline > $O/prof_bench.json 2> $O/prof.err; echo "prof rc=$?"
@@ -36,7 +36,7 @@ then cp $O/xattn_pmc.json profiles/xattn_pmc.json; cp $O/${TAG}_pmc.json profile
 else echo "PMC passes incomplete: profiles/ left untouched"; fi
 timeout 600 python bench.py > $O/bench_final.json 2> $O/bench_final.err; echo "bench final rc=$?"; head -c 300 $O/bench_final.json; echo
 # side lines (never the headline)
-timeout 400 python bench.py --compute f16 --write-crc --no-side --no-cpu-baseline > $O/bench_f16.json 2>/dev/null; echo "f16 rc=$?"
+timeout 400 python bench.py --compute f16 --write-crc --dump-tokens $O/bench_tokens_f16.npy --no-side --no-cpu-baseline > $O/bench_f16.json 2>/dev/null; echo "f16 rc=$?"
 timeout 400 python bench.py --xkv-fp8 --write-crc --no-side --no-cpu-baseline > $O/bench_xkv_fp8.json 2>/dev/null; echo "fp8 rc=$?"
 timeout 400 python bench.py --model large-v3-turbo --batch 32 --no-side --no-cpu-baseline > $O/bench_turbo_b32.json 2>/dev/null; echo "turbo rc=$?"
 timeout 400 python bench.py --model small --batch 8 --no-side --no-cpu-baseline > $O/bench_small_b8.json 2>/dev/null; echo "small rc=$?"
