@@ -167,7 +167,7 @@ def test_forced_single_rank_group_runs_the_collective_paths():
     assert p.exitcode == 0
 
 
-def _world4_worker(rank, world, port, q):
+def _world4_worker(rank, world, port, q, n_clips=10):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import torch
@@ -194,8 +194,8 @@ def _world4_worker(rank, world, port, q):
     plan = bucket_plan(sizes, kinds, bucket_bytes, (4, 2))
     want = [specs[k][0] for b in plan for k in b]
     # uneven shards: 10 clips over 4 ranks = 3 + 3 + 2 + 2, padded to the largest shard for the all-gather
-    lo, hi = shard_range(10, r, w)
-    n_max = max(shard_range(10, rr, w)[1] - shard_range(10, rr, w)[0] for rr in range(w))
+    lo, hi = shard_range(n_clips, r, w)
+    n_max = max(shard_range(n_clips, rr, w)[1] - shard_range(n_clips, rr, w)[0] for rr in range(w))
     toks = [[1000 * c + j for j in range(1 + c % 3)] for c in range(lo, hi)] + [[]] * (n_max - (hi - lo))
     allt = gather_tokens(toks, 4)
     q.put((r, bool(ok), order == want, len(plan), allt.tolist(), (lo, hi)))
@@ -229,6 +229,32 @@ def test_world4_uneven_shards_and_multi_dtype_receive_order():
         want = [1000 * c + j for j in range(1 + c % 3)]
         assert tuple(want + [-1] * (4 - len(want))) in rows
     assert allt[8].tolist() == [-1] * 4 and allt[11].tolist() == [-1] * 4   # the padding rows of the 2-clip shards
+
+
+def test_world8_the_scale_runs_rank_count():
+    """Eight ranks - the rank count of the driver's SCALE run and of configs C4 / C5, which no GPU box of this build has ever had
+    (RCCL has executed with one rank only) - over gloo on the CPU: 19 clips = 3 + 3 + 3 + 2 + 2 + 2 + 2 + 2, the multi-dtype bucket
+    plan travelling in 16 bits, every rank receiving in the plan's order, one padded all-gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world4_worker, args=(r, 8, port, q, 19)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in range(8))
+    for p in procs:
+        p.join(90)
+        assert p.exitcode == 0
+    assert [x[5] for x in res] == [(0, 3), (3, 6), (6, 9), (9, 11), (11, 13), (13, 15), (15, 17), (17, 19)]
+    assert all(x[1] for x in res) and all(x[2] for x in res)
+    assert all(x[4] == res[0][4] for x in res)
+    allt = np.array(res[0][4])
+    assert allt.shape == (24, 4)               # 8 ranks x the largest shard (3 rows)
+    rows = {tuple(t) for t in allt.tolist()}
+    for c in range(19):
+        want = [1000 * c + j for j in range(1 + c % 3)]
+        assert tuple(want + [-1] * (4 - len(want))) in rows
+    assert sum(t == [-1] * 4 for t in allt.tolist()) == 5   # one padding row in each of the five 2-clip shards
 
 
 def test_missing_master_port_fails_fast_for_a_real_group(monkeypatch):
