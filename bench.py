@@ -737,7 +737,7 @@ def main():
                 t8, m = timed(lambda: one_pass(e2), B)
                 t8 = tok_array(t8)
                 m.update({"dtype": args.compute + " + e4m3 cross-KV cache", "phase_ms": {k_: round(v_, 2) for k_, v_ in e2.phase_ms().items()},
-                          "vs_f32_parity_tokens": token_agreement(t8, "bench_tokens_f32.npy", args.model, "noise"),
+                          "vs_f32_parity_tokens": token_agreement(t8, "bench_tokens_f32.npy", args.model, args.clips),
                           "vs_headline_tokens_rows_identical": int((t8 == np.asarray(toks[:B], dtype=np.int32)).all(axis=1).sum()),
                           "note": "opt-in serving mode (ttasr_set_option xkv_fp8), never the headline"})
                 side["xkv_fp8"] = m
@@ -751,7 +751,7 @@ def main():
                 t16 = tok_array(t16)
                 import zlib
                 m.update({"dtype": "f16", "phase_ms": {k_: round(v_, 2) for k_, v_ in e3.phase_ms().items()}, "tokens_crc32": zlib.crc32(np.ascontiguousarray(t16).tobytes()) & 0xFFFFFFFF,
-                          "vs_f32_parity_tokens": token_agreement(t16, "bench_tokens_f32.npy", args.model, "noise"),
+                          "vs_f32_parity_tokens": token_agreement(t16, "bench_tokens_f32.npy", args.model, args.clips),
                           "note": "compute_type float16 = the reference's GPU setting (asr_core.py:141); same kernels templated on the storage type"})
                 side["f16"] = m
                 e3.close()
