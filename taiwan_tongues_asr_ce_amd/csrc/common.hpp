@@ -198,6 +198,8 @@ template <typename T16> void launch_gemm_bf16_v3(const GemmArgs& g, hipStream_t 
 bool gemm_bf16_v3_ok(const GemmArgs& g);
 template <typename T16> void launch_gemm_bf16_v4(const GemmArgs& g, hipStream_t s);   // persistent form of v3 (T-output epilogues)
 bool gemm_bf16_v4_ok(const GemmArgs& g);
+template <typename T16> bool launch_gemm_bf16_v5(const GemmArgs& g, hipStream_t s);   // v4 with the last partial round re-tiled (shorter tiles); false = no gain for this shape
+bool gemm_bf16_v5_ok(const GemmArgs& g);
 
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);

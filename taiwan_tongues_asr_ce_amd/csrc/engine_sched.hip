@@ -14,7 +14,12 @@ void gemm(ttasr_ctx* c, const GemmArgs& g) {
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
       const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
       // persistent form (round 4): pays once a workgroup has several tiles to walk (>= 2 per CU)
-      if ((v ? v == 4 : (c->gemm_persistent && tiles_v3 >= 512)) && gemm_bf16_v4_ok(g)) { launch_gemm_bf16_v4<T>(g, c->cur); return; }
+      if ((v ? v == 4 : (c->gemm_persistent && tiles_v3 >= 512)) && gemm_bf16_v4_ok(g)) {
+        // round 5: the same persistent kernel with the last partial round of workgroups re-tiled into shorter tiles where that pays
+        if (c->gemm_tail && v != 4 && launch_gemm_bf16_v5<T>(g, c->cur)) return;
+        launch_gemm_bf16_v4<T>(g, c->cur);
+        return;
+      }
       if ((v ? v == 3 || v == 4 : tiles_v3 >= 128) && gemm_bf16_v3_ok(g)) { launch_gemm_bf16_v3<T>(g, c->cur); return; }
       if (v != 1 && gemm_bf16_v2_ok(g)) { launch_gemm_bf16_v2<T>(g, c->cur); return; }
       if (gemm_bf16_fast_ok(g)) { launch_gemm_bf16_fast<T>(g, c->cur); return; }

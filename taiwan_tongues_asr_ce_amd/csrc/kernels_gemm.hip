@@ -839,6 +839,240 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs g, int ti
 #undef V4_STAGE
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_bf16_v5 (round 5): v4 whose LAST partial round of workgroups is re-tiled ("give the surplus tiles to
+// ALL CUs by splitting them along M ... no f32 partials").  The rows are cut into a FULL region of 256-row m-tiles whose tile count
+// fills whole rounds of the 256 persistent workgroups, and a TAIL region of shorter tiles - 192 or 128 rows (6 or 4 row blocks
+// of 16 per wave group instead of 8), all 256 columns - chosen so that the tail's tile count fits ONE round: e.g. out-proj / fc2 at
+// B = 32 (940 tiles = 3.67 rounds -> 4): 765 full tiles (2.99 rounds) + 230 tiles of 192 rows (one round of ~0.78 of a tile).
+// A shorter tile is the same tile body with fewer row blocks (template MI): the A image is still staged 256 rows deep (the extra
+// rows are the next tile's, read only), every output element sees the same K loop in the same order: bit-identical to v3 / v4.
+// ------------------------------------------------------------------------------------------------
+template <typename T16, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmArgs g, int tiles_m, int tiles_n, int tail_tiles_m, int tail_mi) {
+  constexpr int BM = 256, BN = 256, BK = 32;
+  constexpr int OP_BYTES = BM * BK * 2, STAGE_BYTES = 2 * OP_BYTES;
+  constexpr bool ACT = EPI & 1, HS = EPI & 8;
+  static_assert((EPI & ~9) == 0, "v4 carries the T-output epilogues only");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // tiles_m = 256-row m-tiles of the FULL region; the rows behind it are the TAIL region: tail_tiles_m m-tiles of tail_mi * 32 rows
+  // (tail_mi = row blocks of 16 per wave group: 6 -> 192-row tiles, 4 -> 128-row tiles).  groups == 1 (gemm_bf16_v5_ok).
+  const int n_full = tiles_m * tiles_n, n_tail = tail_tiles_m * tiles_n;
+  // static schedule: the workgroups that share an XCD (bid % 8) own one contiguous chunk of the full tiles and one of the tail
+  // tiles; a workgroup walks its full tiles round-robin (slot, slot + per_xcd, ...), then its tail tiles from the OTHER end of
+  // the slot order (the workgroups that got one full tile less take the tail tiles first)
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;  // workgroups of this class
+  auto chunk = [&](int n, int& lo, int& hi) { const int q = n >> 3, r = n & 7; lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q; hi = lo + (xcd < r ? q + 1 : q); };
+  int fb, fe, tb, te;
+  chunk(n_full, fb, fe);
+  chunk(n_tail, tb, te);
+  // tile ids: [0, n_full) full tiles, n_full + [0, n_tail) tail tiles
+  auto first_tail = [&]() { const int t = tb + (per_xcd - 1 - slot); return t < te ? n_full + t : -1; };
+  auto next_of = [&](int id) {
+    const int nx = id + per_xcd;
+    if (id < n_full) return nx < fe ? nx : first_tail();
+    return nx - n_full < te ? nx : -1;
+  };
+  const bf16_t* A = (const bf16_t*)g.A;
+  const bf16_t* W = (const bf16_t*)g.W;
+  const GemmEpi& e = g.epi;
+  const int srow = lane >> 2, sslot = lane & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t frag_off = (uint32_t)(fr * 64 + ((fq ^ v3_h((fr >> 2) & 3)) << 4));
+  const uint32_t w_off = lds_base + OP_BYTES + wn * 64 * 64 + frag_off;
+  const int nt = g.K / BK;  // >= 4
+  constexpr int GM = 4;
+
+  int m0 = 0, n0 = 0;
+  const float* bias_g = e.bias;
+  const bf16_t* a_src[2];
+  const bf16_t* w_src[2];
+  int mi_placed = 8;         // row blocks per wave group of the tile place() was last called for
+  auto place = [&](int tile) {   // tile id -> (m0, n0), staging source pointers (the v3 raster inside each region)
+    int tm_n = tiles_m, base_row = 0, rows_per_tile = BM;
+    mi_placed = 8;
+    if (tile >= n_full) { tile -= n_full; tm_n = tail_tiles_m; base_row = tiles_m * BM; rows_per_tile = tail_mi * 32; mi_placed = tail_mi; }
+    const int band = tile / (GM * tiles_n);
+    const int rows_in_band = min(GM, tm_n - band * GM);
+    const int in_band = tile - band * GM * tiles_n;
+    const int tn = in_band / rows_in_band;
+    const int tm = band * GM + (in_band - tn * rows_in_band);
+    m0 = base_row + tm * rows_per_tile; n0 = tn * BN;
+    // every wave stages its 2 + 2 pieces for EVERY tile (the counted waits rely on it), but the A pieces of a short tile that lie
+    // past its last row re-read that one row (one cache line per piece instead of sixteen): a short tile does not pay for A rows
+    // it does not use - what fc2, whose 492 MB A operand streams from beyond L2, needs to gain anything
+    const int row_lim = min(g.M - 1, m0 + rows_per_tile - 1);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (wave * 2 + p) * 16 + srow;
+      const int chunk = sslot ^ v3_h((row >> 2) & 3);
+      a_src[p] = A + (int64_t)min(m0 + row, row_lim) * g.lda + chunk * 8;
+      w_src[p] = W + (int64_t)(n0 + row) * g.ldw + chunk * 8;
+    }
+  };
+#define V4_STAGE(slot_, k0_)                                                                   \
+  do {                                                                                         \
+    char* base_ = smem + (slot_) * STAGE_BYTES;                                                \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                            \
+      glds16(a_src[p] + (k0_), base_ + (wave * 2 + p) * 1024);                                 \
+      glds16(w_src[p] + (k0_), base_ + OP_BYTES + (wave * 2 + p) * 1024);                      \
+    }                                                                                          \
+  } while (0)
+  auto load_bias = [&](float4 (&b4)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b4[j] = *(const float4*)(bias_g + n0 + wn * 64 + fq * 4 + j * 16);   // bias != nullptr (gemm_bf16_v4_ok)
+    // waited for HERE, while nothing else is in flight: no later use of these registers may drain the LDS-DMA queue
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(b4[0].x), "+v"(b4[0].y), "+v"(b4[0].z), "+v"(b4[0].w), "+v"(b4[1].x), "+v"(b4[1].y),
+                 "+v"(b4[1].z), "+v"(b4[1].w), "+v"(b4[2].x), "+v"(b4[2].y), "+v"(b4[2].z), "+v"(b4[2].w), "+v"(b4[3].x),
+                 "+v"(b4[3].y), "+v"(b4[3].z), "+v"(b4[3].w));
+  };
+
+  int tile = fb + slot < fe ? fb + slot : first_tail();
+  if (tile < 0) return;
+  place(tile);
+  float4 bias4[4];
+  load_bias(bias4);
+  V4_STAGE(0, 0);
+  V4_STAGE(1, BK);
+  V4_STAGE(2, 2 * BK);
+  int carry = 0;   // stores of the previous tile's epilogue (2 per row block) that sit behind the three prefetched stages
+  // "own pieces of the wanted stage landed": everything but the 4 youngest pieces and the carried stores (issue order)
+#define V5_WAIT_CARRY()                                                          \
+  do {                                                                           \
+    if (carry == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");           \
+    else if (carry == 12) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      \
+    else if (carry == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        \
+  } while (0)
+
+  // one tile of MI row blocks per wave group (MI = 8: the 256 x 256 tile of v4; 6 / 4: the shorter tiles of the tail region);
+  // returns false after the workgroup's last tile
+  auto run_tile = [&](auto mi_tag) -> bool {
+    constexpr int MI = decltype(mi_tag)::value;
+    const uint32_t a_off = lds_base + wm * (MI * 16) * 64 + frag_off;
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // stages 0 and 1 landed (own pieces); queue behind them: stage 2 (4) [+ the carried stores]
+    V5_WAIT_CARRY();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier behind
+    for (int t = 0; t < nt; ++t) {
+      // ---- phase A ----
+      if (t + 2 < nt) {
+        // own pieces of stage t + 1 landed; queue behind them: stage t + 2 (4), and for t < 2 of a carried tile its stores
+        // (t = 0: [stage 2][stores]; t = 1: [stores][stage 3] - from t = 2 on the stores are older than what is waited for)
+        if (t < 2) V5_WAIT_CARRY(); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < nt) V4_STAGE((t + 3) & 3, (t + 3) * BK);
+      s16x8 a[MI], b[4];
+      const uint32_t so = (uint32_t)((t & 3) * STAGE_BYTES);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(w_off + so + j * 16 * 64));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(a_off + so + i * 16 * 64));
+      if constexpr (MI == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                       "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else if constexpr (MI == 6)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B ----
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // balance the barrier count: every fragment read of this tile is drained
+    // ---- this tile's output coordinates (before the staging pointers move on) ----
+    const int nbase = n0 + wn * 64 + fq * 4;
+    int64_t coloff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = nbase + j * 16;
+      if (HS) {
+        const int which = n / e.hs_d, nn = n - which * e.hs_d;
+        coloff[j] = (int64_t)which * e.hs_which + (int64_t)(nn >> 6) * e.hs_T * 64 + (nn & 63);
+      } else coloff[j] = n;
+    }
+    const int mrow0 = m0 + wm * (MI * 16) + fr;
+    // ---- next tile: bias (waited for now), then its first three stages into the free ring ----
+    const int next = next_of(tile);
+    const bool has_next = next >= 0;
+    float4 bias_next[4];
+    if (has_next) {
+      place(next);
+      load_bias(bias_next);
+      V4_STAGE(0, 0);
+      V4_STAGE(1, BK);
+      V4_STAGE(2, 2 * BK);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue of this tile: VALU + 2 unconditional 16-byte stores per row block and lane ----
+    const bool odd = (fq & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = min(mrow0 + i * 16, g.M - 1);
+      int64_t rowoff;
+      if (HS) {
+        const int bb = m / e.hs_T, tt = m - bb * e.hs_T;
+        rowoff = ((int64_t)bb * e.hs_H * e.hs_T + tt) * 64;
+      } else rowoff = (int64_t)m * e.ldc;
+      uint2 pk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = acc[i][j];
+        v[0] += bias4[j].x; v[1] += bias4[j].y; v[2] += bias4[j].z; v[3] += bias4[j].w;
+        if (ACT) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = gelu_fast(v[t]);
+        }
+        pk[j].x = N16<T16>::pk(v[0], v[1]);
+        pk[j].y = N16<T16>::pk(v[2], v[3]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 4; jp += 2) {
+        auto sx = __builtin_amdgcn_permlane16_swap(pk[jp].x, pk[jp + 1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane16_swap(pk[jp].y, pk[jp + 1].y, false, false);
+        const uint4 w = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const int jj = odd ? jp + 1 : jp;
+        *(uint4*)((bf16_t*)e.out_t + rowoff + coloff[jj] - (odd ? 4 : 0)) = w;
+      }
+    }
+    if (!has_next) return false;
+    tile = next;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = bias_next[j];
+    carry = 2 * MI;
+    return true;
+  };
+  int mi_cur = mi_placed;
+  for (;;) {
+    bool more;
+    if (mi_cur == 8) more = run_tile(std::integral_constant<int, 8>{});
+    else if (mi_cur == 6) more = run_tile(std::integral_constant<int, 6>{});
+    else more = run_tile(std::integral_constant<int, 4>{});
+    if (!more) break;
+    mi_cur = mi_placed;   // place(next) ran inside run_tile
+  }
+#undef V5_WAIT_CARRY
+#undef V4_STAGE
+}
+
 bool gemm_bf16_v4_ok(const GemmArgs& g) {
   const int code = v3_epi_code(g.epi);
   return (code == 0 || code == 1 || code == 8) && g.batch <= 1 && g.groups >= 1 && g.epi.bias != nullptr && gemm_bf16_v3_ok(g);
@@ -856,6 +1090,9 @@ static void tiles_attrs() {
 #define TTASR_V4_ATTR(E_) hipFuncSetAttribute((const void*)gemm_bf16_v4_kernel<T16, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768)
   TTASR_V3_ATTR(0); TTASR_V3_ATTR(1); TTASR_V3_ATTR(18); TTASR_V3_ATTR(21); TTASR_V3_ATTR(8);
   TTASR_V4_ATTR(0); TTASR_V4_ATTR(1); TTASR_V4_ATTR(8);
+#define TTASR_V5_ATTR(E_) hipFuncSetAttribute((const void*)gemm_bf16_v5_kernel<T16, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768)
+  TTASR_V5_ATTR(0); TTASR_V5_ATTR(1); TTASR_V5_ATTR(8);
+#undef TTASR_V5_ATTR
 #undef TTASR_V3_ATTR
 #undef TTASR_V4_ATTR
 }
@@ -887,6 +1124,57 @@ void launch_gemm_bf16_v4(const GemmArgs& g, hipStream_t s) {
 }
 template void launch_gemm_bf16_v4<bf16_t>(const GemmArgs&, hipStream_t);
 template void launch_gemm_bf16_v4<f16_t>(const GemmArgs&, hipStream_t);
+
+// ---- v5: where to cut the rows, and how tall the tail's tiles are ----
+// Makespan model of the static schedule (per-XCD chunks, round-robin over the XCD's workgroups), in units of one 256 x 256 tile;
+// a 192-row tile is priced 0.80, a 128-row tile 0.62 (measured: see DESIGN 4.11).  A plan must beat the plain tiling by more than
+// 0.15 tile-times and its tail must fit one round.
+struct V5Plan { int full_m = 0, tail_m = 0, tail_mi = 0; };
+static bool v5_plan(int M, int tiles_n, int cus, V5Plan& plan) {
+  if (cus < 8 || cus % 8) return false;
+  const int tm_all = (M + 255) / 256, per = cus / 8;
+  auto rounds = [&](int n) { return ((n + 7) / 8 + per - 1) / per; };
+  double best = rounds(tm_all * tiles_n) - 0.15;
+  bool found = false;
+  for (int mi = 6; mi >= 4; mi -= 2) {
+    const double cost = mi == 6 ? 0.80 : 0.62;
+    for (int full_m = tm_all - 1; full_m >= 0 && full_m >= tm_all - 96; --full_m) {
+      const int tail_rows = M - full_m * 256;
+      if (tail_rows <= 0) continue;
+      const int tail_m = (tail_rows + mi * 32 - 1) / (mi * 32), nt = tail_m * tiles_n;
+      if (nt > cus) break;                       // taller full region -> fewer tail tiles: nothing further down fits either
+      const double est = rounds(full_m * tiles_n) + cost * rounds(nt);
+      if (est < best) { best = est; plan.full_m = full_m; plan.tail_m = tail_m; plan.tail_mi = mi; found = true; }
+    }
+  }
+  return found;
+}
+bool gemm_bf16_v5_ok(const GemmArgs& g) { return g.groups <= 1 && gemm_bf16_v4_ok(g); }
+template <typename T16, int EPI>
+static void launch_v5(const GemmArgs& g, const V5Plan& p, int cus, hipStream_t s) {
+  const int tiles_n = g.N / 256;
+  const int grid = std::min((p.full_m + p.tail_m) * tiles_n, cus);
+  if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "gemm_bf16_v5_kernel<%s, %d> grid %d", sig_type<T16>(), EPI, grid * 512);
+  hipLaunchKernelGGL((gemm_bf16_v5_kernel<T16, EPI>), dim3(grid), dim3(512), 4 * 32768, s, g, p.full_m, tiles_n, p.tail_m, p.tail_mi);
+}
+// false: no plan beats the plain tiling for this shape (the caller launches v4)
+template <typename T16>
+bool launch_gemm_bf16_v5(const GemmArgs& g, hipStream_t s) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  const int cus = g_v4_cus[dev & 63];
+  V5Plan p;
+  if (!gemm_bf16_v5_ok(g) || !v5_plan(g.M, g.N / 256, cus, p)) return false;
+  switch (v3_epi_code(g.epi)) {
+    case 0: launch_v5<T16, 0>(g, p, cus, s); break;
+    case 1: launch_v5<T16, 1>(g, p, cus, s); break;
+    case 8: launch_v5<T16, 8>(g, p, cus, s); break;
+    default: return false;
+  }
+  return true;
+}
+template bool launch_gemm_bf16_v5<bf16_t>(const GemmArgs&, hipStream_t);
+template bool launch_gemm_bf16_v5<f16_t>(const GemmArgs&, hipStream_t);
 
 bool gemm_bf16_fast_ok(const GemmArgs& g) {
   return g.N % 128 == 0 && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.M >= 1 &&

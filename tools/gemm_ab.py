@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the encoder GEMM kernels on one GPU (large-v3 geometry, B = 32): option enc_gemm = 3 (256x256 tiles, one workgroup per
-tile) against 4 (the same tile body as persistent workgroups), interleaved rounds in one process, plus a bit-identity check of the
+tile) against 4 (the same tile body as persistent workgroups) and 0 (round 5: the automatic choice = persistent workgroups with the
+last partial round re-tiled into shorter tiles where that pays), interleaved rounds in one process, plus a bit-identity check of the
 whole encoder output and the in-situ class times of a real encoder pass under each.
 
     python tools/gemm_ab.py [--rounds 4] [--batch 32]
@@ -21,7 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", default="large-v3")
-    ap.add_argument("--variants", default="3,4")
+    ap.add_argument("--variants", default="3,4,0")
     ap.add_argument("--no-insitu", action="store_true")
     args = ap.parse_args()
     from taiwan_tongues_asr_ce_amd import synth

@@ -40,7 +40,7 @@ def load(d):
 
 
 def label(name, grid):
-    m = re.search(r"gemm_bf16_v[34]_kernel<(?:[A-Za-z_0-9 ]+, )?(\d+)>", name)   # <storage type, EPI>; v4 = the persistent form (round 4)
+    m = re.search(r"gemm_bf16_v[345]_kernel<(?:[A-Za-z_0-9 ]+, )?(\d+)>", name)   # <storage type, EPI>; v4 = the persistent form (round 4)
     if m:
         epi = int(m.group(1))
         return {0: "enc GEMM bias -> bf16 (EPI 0: qkv, out-proj, fc2)", 1: "enc GEMM bias + GELU -> bf16 (EPI 1: fc1, conv1)",
