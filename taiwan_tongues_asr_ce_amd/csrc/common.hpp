@@ -206,6 +206,13 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, T* 
 // x += delta (the T-typed output of the preceding out-proj / fc2 GEMM), then LayerNorm(x) -> out; delta may alias out
 template <typename T>
 void launch_layernorm_add(float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
+// round 5: out = LayerNorm(x + delta) without updating x ... and the LayerNorm that later folds that delta and a second one in:
+// x = (x + delta) + delta2 (delta2 may alias out).  Same f32 additions in the same order as two launch_layernorm_add calls.
+template <typename T>
+void launch_layernorm_peek(const float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s);
+template <typename T>
+void launch_layernorm_add2(float* x, const T* delta, const T* delta2, const float* gamma, const float* beta, T* out, int rows, int d,
+                           hipStream_t s);
 // decode-step LayerNorm, one workgroup per row (kernels_misc.hip), that first completes the residual row:
 //   slab form:  x_out[row] = x[row] + bias + slab[0][row] + ... + slab[n_slab-1][row]   (fixed order, no atomics)
 //   embed form (tok != nullptr): x_out[row] = emb[tok[row]] + pos[*step]

@@ -127,16 +127,25 @@ int run_encoder(ttasr_ctx* c, int B) {
   // those GEMMs' epilogues - exposed at one workgroup per CU - was what held out-proj at 0.66 PF/s.
   // f32 parity mode keeps the residual epilogue.
   const bool delta = sizeof(T) == 2 && !c->force_basic && !c->enc_res_epilogue;
-  bool pending = false;  // a delta sits in h and has not been added to x yet
-  auto ln = [&](const float* g_, const float* b_, void* out) {
-    if (pending) launch_layernorm_add<T>(c->x, (const T*)c->h, g_, b_, (T*)out, R, d, s);
+  // Round 5 (option enc_ln_defer): the out-projection's delta goes to the (dead) qkv buffer and is NOT folded into x by the
+  // LayerNorm that follows it (which only "peeks": normalises x + delta); the next LayerNorm - after fc2, whose delta sits in h -
+  // folds both in, x = (x + delta_attn) + delta_ffn: one f32 read-modify-write of the residual stream per layer instead of two
+  // (LayerNorm traffic per layer and element 22 B instead of 24), bit-identical.
+  const bool defer = delta && c->enc_ln_defer;
+  bool pending = false;       // a delta sits in h and has not been added to x yet
+  bool pending_attn = false;  // defer: the out-projection's delta sits in the qkv buffer and has not been added to x yet
+  auto ln = [&](const float* g_, const float* b_, void* out, bool after_attn = false) {
+    if (pending_attn && after_attn) launch_layernorm_peek<T>(c->x, (const T*)c->qkv, g_, b_, (T*)out, R, d, s);
+    else if (pending_attn && pending) { launch_layernorm_add2<T>(c->x, (const T*)c->qkv, (const T*)c->h, g_, b_, (T*)out, R, d, s); pending_attn = false; }
+    else if (pending) launch_layernorm_add<T>(c->x, (const T*)c->h, g_, b_, (T*)out, R, d, s);
     else launch_layernorm<T>(c->x, g_, b_, (T*)out, R, d, s);
-    pending = false;
+    if (!after_attn || !pending_attn) pending = false;
     enc_mark(c, EC_LN);
   };
   auto residual_gemm = [&](const void* A, const void* W, const float* bias, int K, int cls) {
     GemmArgs g = lin_args<T>(A, W, R, d, K); g.epi.bias = bias;
-    if (delta) { g.epi.out_t = c->h; pending = true; }
+    if (delta && defer && cls == EC_OUT) { g.epi.out_t = c->qkv; pending_attn = true; }   // q / k / v are dead once attention has run
+    else if (delta) { g.epi.out_t = c->h; pending = true; }
     else { g.epi.residual = c->x; g.epi.out_f32 = c->x; }
     gemm<T>(c, g);
     enc_mark(c, cls);
@@ -153,7 +162,7 @@ int run_encoder(ttasr_ctx* c, int B) {
     if (!flash) launch_enc_attn_simple<T>((const T*)c->qkv, (T*)c->att, B, T_, c->H, s);
     enc_mark(c, EC_ATTN);
     residual_gemm(c->att, L.wo, L.bo, d, EC_OUT);
-    ln(L.ln2g, L.ln2b, c->h);
+    ln(L.ln2g, L.ln2b, c->h, true);
     { GemmArgs g = lin_args<T>(c->h, L.w1, R, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = c->mid; gemm<T>(c, g); }
     enc_mark(c, EC_FC1);
     residual_gemm(c->mid, L.w2, L.b2, ffn, EC_FC2);

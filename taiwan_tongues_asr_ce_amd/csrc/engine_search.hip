@@ -70,6 +70,7 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   else if (key == "enc_gemm_persistent") c->gemm_persistent = on;
   else if (key == "xkv_grouped") c->xkv_grouped = on;
   else if (key == "enc_gemm_tail") c->gemm_tail = on;
+  else if (key == "enc_ln_defer") c->enc_ln_defer = on;
   else if (key == "dec_narrow_blocks") { if (c->weights_packed && on != c->dec_narrow) return 1; c->dec_narrow = on; }   // a layout choice: before the first weight arrives
   else if (key == "ksplit_out") { if (v < 0 || v > 16) return 1; c->ks_want[0] = v; }
   else if (key == "ksplit_q") { if (v < 0 || v > 16) return 1; c->ks_want[1] = v; }

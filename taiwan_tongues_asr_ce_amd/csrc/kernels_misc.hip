@@ -167,10 +167,15 @@ template void launch_mel_transpose<f16_t>(const float*, f16_t*, int, int, int, h
 // Moving the residual add out of those GEMMs' epilogues (a 492 MB f32 read-modify-write per GEMM at B = 32, exposed at one
 // workgroup per CU) into this HBM-streaming kernel lets them run the plain "bias -> T" epilogue.  delta may alias `out`
 // (each lane reads its delta chunks before it writes the same positions of the output).
-template <typename T, int NV, bool ADD>  // NV = float4 per lane kept in registers: d <= 256 * NV
+// Round 5 - two more forms that save a third of the f32 residual round trips of an encoder layer (bit-identical: the same two
+// f32 additions in the same order):  ADD = 2: normalise x + delta WITHOUT writing the sum back (the LayerNorm after the attention
+// out-projection: its delta stays in its buffer);  ADD = 3: x = (x + delta) + delta2, written back, then normalised (the next
+// LayerNorm, after fc2: it folds both deltas of the layer in).  Per layer and element 8 + 14 bytes instead of 12 + 12.
+template <typename T, int NV, int ADD>  // NV = float4 per lane kept in registers: d <= 256 * NV
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* out, int rows, int d,
-                                                        const T* delta, float* x_out /* ADD: the same rows as x */) {
+                                                        const T* delta, float* x_out /* ADD 1 / 3: the same rows as x */,
+                                                        const T* delta2) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float4* xr = (const float4*)(x + (int64_t)row * d);
@@ -185,24 +190,39 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     gm[j] = ((const float4*)gamma)[i];
     bt[j] = ((const float4*)beta)[i];
   }
-  if constexpr (ADD) {
-    float4 dl[NV];
+  if constexpr (ADD != 0) {
+    auto load_delta = [&](const T* dp, float4 (&dl)[NV]) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int i = min(lane + 64 * j, nv - 1);
-      if constexpr (sizeof(T) == 4) {
-        dl[j] = ((const float4*)(delta + (int64_t)row * d))[i];
-      } else {
-        const uint2 t = ((const uint2*)(delta + (int64_t)row * d))[i];
-        N16<T>::up2(t.x, dl[j].x, dl[j].y);
-        N16<T>::up2(t.y, dl[j].z, dl[j].w);
+      for (int j = 0; j < NV; ++j) {
+        const int i = min(lane + 64 * j, nv - 1);
+        if constexpr (sizeof(T) == 4) {
+          dl[j] = ((const float4*)(dp + (int64_t)row * d))[i];
+        } else {
+          const uint2 t = ((const uint2*)(dp + (int64_t)row * d))[i];
+          N16<T>::up2(t.x, dl[j].x, dl[j].y);
+          N16<T>::up2(t.y, dl[j].z, dl[j].w);
+        }
       }
-    }
-    float4* xo = (float4*)(x_out + (int64_t)row * d);
+    };
+    float4 dl[NV];
+    load_delta(delta, dl);
+    if constexpr (ADD == 3) {
+      float4 d2[NV];
+      load_delta(delta2, d2);     // both deltas requested before either is used
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      v[j].x += dl[j].x; v[j].y += dl[j].y; v[j].z += dl[j].z; v[j].w += dl[j].w;
-      if (lane + 64 * j < nv) xo[lane + 64 * j] = v[j];
+      for (int j = 0; j < NV; ++j) {
+        v[j].x += dl[j].x; v[j].y += dl[j].y; v[j].z += dl[j].z; v[j].w += dl[j].w;
+        v[j].x += d2[j].x; v[j].y += d2[j].y; v[j].z += d2[j].z; v[j].w += d2[j].w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { v[j].x += dl[j].x; v[j].y += dl[j].y; v[j].z += dl[j].z; v[j].w += dl[j].w; }
+    }
+    if constexpr (ADD != 2) {
+      float4* xo = (float4*)(x_out + (int64_t)row * d);
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (lane + 64 * j < nv) xo[lane + 64 * j] = v[j];
     }
   }
   float s = 0.f;
@@ -237,24 +257,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
   }
 }
-template <typename T, bool ADD>
+template <typename T, int ADD>
 static void launch_layernorm_impl(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, const T* delta,
-                                  float* x_out, hipStream_t s) {
+                                  float* x_out, hipStream_t s, const T* delta2 = nullptr) {
   dim3 grid((rows + 3) / 4), block(256);
-  if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
-  else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
-  else if (d <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
-  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
-  else hipLaunchKernelGGL((layernorm_kernel<T, 5, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out);
+  if (d <= 256) hipLaunchKernelGGL((layernorm_kernel<T, 1, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out, delta2);
+  else if (d <= 512) hipLaunchKernelGGL((layernorm_kernel<T, 2, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out, delta2);
+  else if (d <= 768) hipLaunchKernelGGL((layernorm_kernel<T, 3, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out, delta2);
+  else if (d <= 1024) hipLaunchKernelGGL((layernorm_kernel<T, 4, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out, delta2);
+  else hipLaunchKernelGGL((layernorm_kernel<T, 5, ADD>), grid, block, 0, s, x, gamma, beta, out, rows, d, delta, x_out, delta2);
 }
 template <typename T>
 void launch_layernorm(const float* x, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
-  launch_layernorm_impl<T, false>(x, gamma, beta, out, rows, d, nullptr, nullptr, s);
+  launch_layernorm_impl<T, 0>(x, gamma, beta, out, rows, d, nullptr, nullptr, s);
 }
 template <typename T>
 void launch_layernorm_add(float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
-  launch_layernorm_impl<T, true>(x, gamma, beta, out, rows, d, delta, x, s);
+  launch_layernorm_impl<T, 1>(x, gamma, beta, out, rows, d, delta, x, s);
 }
+// out = LayerNorm(x + delta); x itself is NOT updated (the caller folds delta in later: launch_layernorm_add2)
+template <typename T>
+void launch_layernorm_peek(const float* x, const T* delta, const float* gamma, const float* beta, T* out, int rows, int d, hipStream_t s) {
+  launch_layernorm_impl<T, 2>(x, gamma, beta, out, rows, d, delta, nullptr, s);
+}
+// x = (x + delta) + delta2; out = LayerNorm(x).  delta2 may alias out.
+template <typename T>
+void launch_layernorm_add2(float* x, const T* delta, const T* delta2, const float* gamma, const float* beta, T* out, int rows, int d,
+                           hipStream_t s) {
+  launch_layernorm_impl<T, 3>(x, gamma, beta, out, rows, d, delta, x, s, delta2);
+}
+#define TTASR_LN_EXTRA(T_)                                                                                                         \
+  template void launch_layernorm_peek<T_>(const float*, const T_*, const float*, const float*, T_*, int, int, hipStream_t);         \
+  template void launch_layernorm_add2<T_>(float*, const T_*, const T_*, const float*, const float*, T_*, int, int, hipStream_t)
+TTASR_LN_EXTRA(float); TTASR_LN_EXTRA(bf16_t); TTASR_LN_EXTRA(f16_t);
+#undef TTASR_LN_EXTRA
 template void launch_layernorm_add<float>(float*, const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm_add<bf16_t>(float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, hipStream_t);
 template void launch_layernorm_add<f16_t>(float*, const f16_t*, const float*, const float*, f16_t*, int, int, hipStream_t);
