@@ -371,6 +371,9 @@ def main():
                     help="skip the side modes of the default run (fp16 engine, fp8 cross-KV cache, two contexts in flight): a "
                          "rocprofv3 run then sees only the headline configuration's launches")
     ap.add_argument("--side-steps", type=int, default=4, help="timed steps of every side mode")
+    ap.add_argument("--option", action="append", default=[],
+                    help="key=value passed to ttasr_set_option on every engine before its weights are loaded (A/B runs; the line "
+                         "records them in config.options)")
     ap.add_argument("--clips", default="noise", choices=["noise", "tonal"],
                     help="synthetic clip set of the timed steps (SURVEY.md 8d: 0.1 N(0,1) noise; the tonal set - five sines - is "
                          "also measured as a side number by the default run)")
@@ -399,6 +402,10 @@ def main():
     compute = {"bf16": COMPUTE_BF16, "f16": COMPUTE_F16, "f32": COMPUTE_F32}[args.compute]
     engines = [Engine(dims, compute, B, device=local) for _ in range(C_)]
     eng = engines[0]
+    for kv in args.option:
+        k_, v_ = kv.split("=", 1)
+        for e_ in engines:
+            e_.set_option(k_, int(v_))
     if args.xkv_fp8:
         if args.compute == "f32":
             raise SystemExit("--xkv-fp8 needs a 16-bit engine")
@@ -648,7 +655,7 @@ def main():
             "config": {"workload": f"whisper-{args.model} geometry (random-init seeded weights), " + (f"{C_} concurrent contexts x " if C_ > 1 else "") + f"{B} x 30 s 16 kHz synthetic "
                                    f"clips per GPU in pinned host memory, H2D + log-mel + encoder + cross-KV + 4-token prompt + "
                                    f"{args.new_tokens} greedy tokens (EOT suppressed), {args.compute}",
-                       "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens,
+                       "clips_per_gpu": B * C_, "contexts_per_gpu": C_, "new_tokens": args.new_tokens, "options": args.option or None,
                        "transport": transport,
                        "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else "") +
                                       (" (ranks share GPUs over gloo: plumbing check, not a scaling number)"

@@ -72,10 +72,6 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess)
     return die(fail(p, TTASR_E_HIP, "hipStreamCreate failed"));
   p->cur = p->stream;
-  if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess)
-    return die(fail(p, TTASR_E_HIP, "hipStreamCreate (copy stream) failed"));
-  for (auto& e : p->copy_ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return die(fail(p, TTASR_E_HIP, "hipEventCreate failed"));
   gemm_vocab_init(device_id);
   gemm_tiles_init(device_id);
   {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
@@ -132,8 +128,6 @@ void ttasr_destroy(ttasr_ctx* c) {
   drop_graphs(c);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->enc_ev) hipEventDestroy(e);
-  for (auto& e : c->copy_ev) if (e) hipEventDestroy(e);
-  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   for (void* p : c->allocs) hipFree(p);
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -192,33 +186,13 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
     if (ns[b] > c->n_samples) ns[b] = c->n_samples;  // trim to one window
   }
   hipEventRecord(c->ev[0], s);
-  bool chunked = false;
   if (!on_device) {
-    bool whole = pcm_stride == c->n_samples;   // full windows back to back (the batch path)
+    bool whole = pcm_stride == c->n_samples;   // full windows back to back (the batch path): ONE copy instead of B
     for (int b = 0; b < B && whole; ++b) whole = ns[b] == c->n_samples;
-    if (whole && B >= 8) {
-      // Round 5: the batch travels in 4 chunks on a copy stream and the log-mel of chunk i runs on the context's stream as soon
-      // as its samples have landed, i.e. under the copy of chunk i + 1 (61 MB at PCIe rate ~1.1 ms, log-mel of 32 clips 1.2 ms:
-      // 2.3 -> ~1.5 ms).  Nothing of a previous call can still read pcm_dev: every call ends with a stream synchronisation.
-      HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
-      const int per = (B + 3) / 4;
-      int n_chunks = 0;
-      for (int b0 = 0; b0 < B; b0 += per, ++n_chunks) {
-        const int nb = std::min(per, B - b0);
-        HIPCHK(c, hipMemcpyAsync(c->pcm_dev + (int64_t)b0 * c->n_samples, pcm + (int64_t)b0 * pcm_stride, (size_t)nb * c->n_samples * 4,
-                                 hipMemcpyHostToDevice, c->copy_stream));
-        HIPCHK(c, hipEventRecord(c->copy_ev[n_chunks], c->copy_stream));
-      }
-      for (int i = 0, b0 = 0; i < n_chunks; ++i, b0 += per) {
-        const int nb = std::min(per, B - b0);
-        HIPCHK(c, hipStreamWaitEvent(s, c->copy_ev[i], 0));
-        launch_mel(c->pcm_dev + (int64_t)b0 * c->n_samples, c->n_samples, c->nsamp_dev + b0, nb, c->M, c->F, c->filters, c->dcos, c->dsin,
-                   c->window, c->mel + (size_t)b0 * c->M * c->F, c->clip_max + b0, s);
-        TT_DISPATCH(c, launch_mel_finish<T>(c->mel + (size_t)b0 * c->M * c->F, c->clip_max + b0,
-                                            (T*)c->mel_t + (size_t)b0 * (c->F + 2) * c->M, nb, c->M, c->F, s));
-      }
-      chunked = true;
-    } else if (whole) {
+    // (Round 5 also built the copy in four chunks on a second stream with the log-mel of chunk i under the copy of chunk i + 1:
+    // mel phase 2.3 -> 1.7 ms - and removed it: a context that owns a SECOND hardware queue makes two PROCESSES sharing one GPU
+    // time-slice instead of overlapping; their decode chains ran 3.2x slower, 565 -> 1 805 ms per 131 steps each.  DESIGN 4.11.)
+    if (whole) {
       HIPCHK(c, hipMemcpyAsync(c->pcm_dev, pcm, (size_t)B * c->n_samples * 4, hipMemcpyHostToDevice, s));
     } else {
       for (int b = 0; b < B; ++b)
@@ -227,11 +201,9 @@ int ttasr_log_mel(ttasr_ctx* c, const float* pcm, int64_t pcm_stride, const int6
     }
     src = c->pcm_dev; stride = c->n_samples;
   }
-  if (!chunked) {
-    HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
-    launch_mel(src, stride, c->nsamp_dev, B, c->M, c->F, c->filters, c->dcos, c->dsin, c->window, c->mel, c->clip_max, s);
-    TT_DISPATCH(c, launch_mel_finish<T>(c->mel, c->clip_max, (T*)c->mel_t, B, c->M, c->F, s));
-  }
+  HIPCHK(c, hipMemcpyAsync(c->nsamp_dev, ns.data(), B * 8, hipMemcpyHostToDevice, s));
+  launch_mel(src, stride, c->nsamp_dev, B, c->M, c->F, c->filters, c->dcos, c->dsin, c->window, c->mel, c->clip_max, s);
+  TT_DISPATCH(c, launch_mel_finish<T>(c->mel, c->clip_max, (T*)c->mel_t, B, c->M, c->F, s));
   hipEventRecord(c->ev[1], s);
   if (out_mel) HIPCHK(c, hipMemcpyAsync(out_mel, c->mel, (size_t)B * c->M * c->F * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));

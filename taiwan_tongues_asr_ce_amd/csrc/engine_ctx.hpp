@@ -127,8 +127,6 @@ struct ttasr_ctx {
   bool no_prefill = false;  // option prefill = 0: feed prompts token by token (A/B testing)
   bool prefill_tiled = false;  // option prefill_tiled: tiled encoder GEMMs in the prefill pass whatever the row count (A/B testing)
   hipEvent_t ev[8]{};
-  hipStream_t copy_stream = nullptr;   // H2D copies of a host PCM batch in 4 chunks, so that the log-mel of chunk i runs under the copy of chunk i + 1
-  hipEvent_t copy_ev[4]{};
   std::string bench_sig;     // signature of the kernel the last ttasr_bench_kernel call launched (ttasr_bench_kernel_signature)
   float phase_ms[4]{0, 0, 0, 0};
   // option enc_kernel_timing: one hipEvent after every launch of run_encoder / run_cross_kv, so the NEXT ttasr_encode also
