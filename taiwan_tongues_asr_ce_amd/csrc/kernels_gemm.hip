@@ -9,6 +9,9 @@
 //                   image (swizzle applied on the SOURCE address, guide rule 21), XCD-aware tile order.
 #include "common.hpp"
 #include <mutex>
+#ifndef TTASR_V5_DMA
+#define TTASR_V5_DMA 0   // where the persistent GEMM issues stage t + 3 (lab builds: 1 / 2 / 3 = variants measured in round 5)
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -970,7 +973,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmArgs g, int ti
         if (t < 2) V5_WAIT_CARRY(); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+#if TTASR_V5_DMA == 0
       if (t + 3 < nt) V4_STAGE((t + 3) & 3, (t + 3) * BK);
+#elif TTASR_V5_DMA == 2
+      if (t + 3 < nt) { char* base_ = smem + ((t + 3) & 3) * STAGE_BYTES;
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) glds16(a_src[p] + (t + 3) * BK, base_ + (wave * 2 + p) * 1024); }
+#endif
       s16x8 a[MI], b[4];
       const uint32_t so = (uint32_t)((t & 3) * STAGE_BYTES);
 #pragma unroll
@@ -989,11 +997,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v5_kernel(GemmArgs g, int ti
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B ----
       __builtin_amdgcn_s_barrier();
+#if TTASR_V5_DMA == 3
+      if (t + 3 < nt) V4_STAGE((t + 3) & 3, (t + 3) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       __builtin_amdgcn_s_setprio(1);
+#if TTASR_V5_DMA == 0 || TTASR_V5_DMA == 3
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
+#else
+#pragma unroll
+      for (int i = 0; i < MI / 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+#if TTASR_V5_DMA == 1
+      if (t + 3 < nt) V4_STAGE((t + 3) & 3, (t + 3) * BK);
+#else
+      if (t + 3 < nt) { char* base_ = smem + ((t + 3) & 3) * STAGE_BYTES;
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) glds16(w_src[p] + (t + 3) * BK, base_ + OP_BYTES + (wave * 2 + p) * 1024); }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = MI / 2; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = N16<T16>::mfma16(b[j], a[i], acc[i][j]);
+#endif
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
