@@ -111,3 +111,46 @@ def test_bench_single_gpu_through_the_forced_rccl_group():
     assert out["n_gpus"] == 1 and out["config"]["transport"] == "nccl"
     assert out["config"]["rank_logits_spread"] == 0.0
     assert out["output_check"]["replay_bit_identical"] is True
+
+
+_SHARE_CHILD = r"""
+import json, sys, time
+sys.path.insert(0, %r)
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import PRESETS, COMPUTE_BF16
+from taiwan_tongues_asr_ce_amd.engine import Engine
+dims = PRESETS["small"]; B = 8
+e = Engine(dims, COMPUTE_BF16, B)
+e.load_weights(synth.iter_weights(dims))
+st = e.special
+prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+opts = e.gen_opts(96, False, suppress_eot=True, check_interval=1 << 20)
+e.log_mel([synth.noise_clip(i) for i in range(B)], want_output=False); e.encode(B); e.generate([prompt] * B, opts)
+time.sleep(max(0.0, float(sys.argv[1]) - time.time()))      # both processes start their timed loop together
+ts = []
+for _ in range(6):
+    t0 = time.perf_counter(); e.generate([prompt] * B, opts); ts.append(time.perf_counter() - t0)
+print(json.dumps({"decode_ms": sorted(ts)[len(ts) // 2] * 1e3}), flush=True)
+"""
+
+
+def test_two_processes_sharing_the_gpu_overlap_their_decode_chains():
+    """Round 5 regression guard.  Several service processes per GPU is a deployment the reference allows (one model per process,
+    api/streaming_asr.py:85-86).  Two such processes' latency-bound decode chains OVERLAP on the GPU (each takes ~1.5 x the time
+    it takes alone) - as long as every context owns exactly ONE stream: with a second stream per context merely existing, the GPU's
+    scheduler time-slices the processes and each ran 3.2 x slower (profiles/r5_second_stream_two_processes.jsonl).
+    whisper-small, 8 clips, 96 greedy tokens: two concurrent processes must each stay under 2.4 x the solo time."""
+    import time
+
+    def run(n):
+        start = time.time() + (25 if n > 1 else 0)
+        ps = [subprocess.Popen([sys.executable, "-c", _SHARE_CHILD % ROOT, str(start)], stdout=subprocess.PIPE, text=True) for _ in range(n)]
+        out = []
+        for p in ps:
+            o, _ = p.communicate(timeout=600)
+            assert p.returncode == 0
+            out.append(json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1])["decode_ms"])
+        return out
+    solo = run(1)[0]
+    both = run(2)
+    assert max(both) < 2.4 * solo, (solo, both)
