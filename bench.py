@@ -789,12 +789,19 @@ def main():
         if world > 1:   # a multi-rank line must say how the ranks talked and prove they hold the same weights
             assert transport is not None and logits_spread is not None and rank_ms is not None and len(rank_ms) == world, \
                 (transport, logits_spread, rank_ms)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     for e_ in engines:
         e_.close()
     if grp:
         dist_barrier(local)
         dist.destroy_process_group()
+    if rank == 0:
+        # the result is the LAST line this process writes: RCCL prints its version banner through C stdio, which is block-buffered
+        # on a pipe and would otherwise land after the result at exit
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
