@@ -15,6 +15,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -723,6 +724,43 @@ def main():
 
             def tok_array(rows):
                 return np.asarray([list(t) + [0] * (args.new_tokens - len(t)) for t in rows], dtype=np.int32)
+            if not args.no_side:
+                # ragged: the headline workload with a token budget PER ROW (seeded, uniform 32 ... new_tokens; the longest row keeps
+                # the full length) - what natural stopping looks like to the kernels ("with fixed N_dec and with natural
+                # EOT"; synthetic weights emit no meaningful EOT, so the lengths are stated: ttasr_generate_capped).  Finished rows
+                # leave the decode step's attention kernels (round 6); `static_batch` = the same budgets with option ragged_exit = 0,
+                # i.e. the static batch of rounds 1-5 where every row streams its cross-KV until the last one ends.
+                lo_ = min(32, args.new_tokens)
+                caps = np.random.Generator(np.random.Philox(key=6)).integers(lo_, args.new_tokens + 1, size=B).astype(np.int32)
+                caps[int(caps.argmax())] = args.new_tokens
+
+                def ragged_pass():
+                    eng.log_mel_host_ptr(pcm_host.data_ptr(), 480000, ns)
+                    eng.encode(B)
+                    return eng.generate([prompt] * B, opts, row_max_new=caps).tokens
+                tr, m = timed(ragged_pass, B)
+                ph_r = eng.phase_ms()
+                eng.set_option("ragged_exit", 0)
+                ts_, m_static = timed(ragged_pass, B)
+                ph_s = eng.phase_ms()
+                eng.set_option("ragged_exit", 1)
+                L_, H_, T_ = dims.dec_layers, dims.n_heads, dims.n_audio_ctx
+                per_row_step = L_ * H_ * 2 * T_ * 128                      # cross-KV bytes one live row streams per decode step (16-bit)
+                waste = L_ * H_ * 256 * 3 * 16                             # a finished row still requests its first K batch (3 rows x 16 B per lane)
+                steps_run = int(caps.max())
+                streamed = float(caps.astype(np.int64).sum()) * per_row_step + float((steps_run - caps.astype(np.int64)).sum()) * waste
+                m.update({
+                    "row_budgets": {"min": int(caps.min()), "max": int(caps.max()), "mean": round(float(caps.mean()), 1), "seed": 6},
+                    "tokens_generated": int(caps.sum()), "tokens_fixed_length": int(B * args.new_tokens),
+                    "decode_ms": round(ph_r["decode"], 2), "decode_ms_fixed_length": round(statistics.median([p_["decode"] for p_ in phases]), 2),
+                    "decode_ms_static_batch_same_budgets": round(ph_s["decode"], 2), "static_batch_audio_s_per_s": m_static["value"],
+                    "decode_ratio_vs_fixed_length": round(ph_r["decode"] / statistics.median([p_["decode"] for p_ in phases]), 4),
+                    "cross_kv_bytes_streamed": streamed, "cross_kv_bytes_static_batch": float(B) * steps_run * per_row_step,
+                    "rows_equal_headline_prefix": int(sum(list(tr[r]) == [int(v_) for v_ in toks[r][:caps[r]]] for r in range(B))),
+                    "rows_equal_static_batch": int(sum(list(tr[r]) == list(ts_[r]) for r in range(B))),
+                    "note": "same 32 x 30 s of audio; a row is finished at its budget (ttasr_generate_capped) and leaves the attention "
+                            "kernels; every row must equal the headline row cut at its budget (rows_equal_headline_prefix = B)"})
+                side["ragged"] = m
             e2 = Engine(dims, compute, B, device=local)
             e2.load_weights(synth.iter_weights(dims))
             engines.append(e2)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libttasr.so")
 SYMBOLS = [
     "ttasr_create", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
     "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_log_mel_windows", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
-    "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
+    "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_capped", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
     "ttasr_set_option", "ttasr_phase_ms", "ttasr_encoder_kernel_ms", "ttasr_bench_kernel", "ttasr_bench_kernel_signature", "ttasr_sync",
 ]
 
@@ -74,6 +74,7 @@ def load() -> C.CDLL:
     lib.ttasr_get_cross_kv.argtypes = [vp, i32, i32, i32, vp]
     lib.ttasr_set_audio_ctx.argtypes = [vp, i32]
     lib.ttasr_generate.argtypes = [vp, i32, i32p, i32p, i32, C.POINTER(GenOpts), i32p, i32p, f32p, f32p]
+    lib.ttasr_generate_capped.argtypes = [vp, i32, i32p, i32p, i32, C.POINTER(GenOpts), i32p, i32p, i32p, f32p, f32p]
     lib.ttasr_generate_beam.argtypes = [vp, i32, i32, i32p, i32, C.POINTER(GenOpts), C.c_float, i32p, i32p, f32p, f32p]
     lib.ttasr_generate_beam_ragged.argtypes = [vp, i32, i32, i32p, i32p, i32p, i32, C.POINTER(GenOpts), C.c_float, i32p, i32p, f32p, f32p]
     lib.ttasr_generate_sample.argtypes = [vp, i32, i32, i32p, i32, C.POINTER(GenOpts), C.c_float, C.c_uint32, i32p, i32p, f32p, f32p]

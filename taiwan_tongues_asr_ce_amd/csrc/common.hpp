@@ -152,6 +152,22 @@ template <class T> __device__ __forceinline__ T* sgpr_pin_ptr(T* p) {
 }
 
 
+// One uniform 32-bit word that an EARLIER kernel wrote (a row's `done` flag), fetched by the SCALAR unit (s_load_dword through the
+// constant address space): it is requested at kernel entry without occupying the vector-memory queue and is waited for with
+// lgkmcnt only where it is first used - a plain load of a possibly-aliased pointer becomes a global_load + s_waitcnt vmcnt(0) in
+// front of everything else (measured in the ISA: one dependent round trip at the top of the kernel).  The scalar cache is
+// invalidated at every kernel boundary, so a value stored by a previous kernel of the stream is what arrives.
+__device__ __forceinline__ int32_t sload_i32(const int32_t* p) {
+  typedef const __attribute__((address_space(4))) int32_t* const_ptr;
+  return *(const_ptr)p;
+}
+// done[row] of the decode batch, REQUESTED here and tested later as `done && raw` (done == nullptr: the caller tracks no finished
+// rows).  The load is unconditional - from `valid`, any 4-byte-aligned device address, when there are no flags - because a load
+// inside an `if (done)` block is waited for at the end of that block, i.e. at once.
+__device__ __forceinline__ int row_done_issue(const int32_t* done, int row, const void* valid) {
+  return sload_i32(done ? done + row : (const int32_t*)valid);
+}
+
 // ---- GEMM epilogue description (shared by every GEMM flavour) ------------------------------------
 // C[m][n] = act(alpha-free acc + bias[n]) (+ rowtab[(m % rowmod)][n]) (+ residual[m][n]); written as f32
 // and/or T.  headsplit != 0 scatters T output into the cross-KV layout [which][b][h][t][64].
@@ -305,6 +321,8 @@ struct DecState {            // device-resident per-row search state
   const int32_t* prompt_len; // [B]
   const uint8_t* mask;       // [V] bit0 suppress, bit1 begin-suppress
   const RuleDyn* dyn;        // [1] overrides RuleParams.{max_prompt, max_new, sot_index, seed} in select_kernel
+  const int32_t* row_cap;    // [B] per-row token budget (round 6, ttasr_generate_capped): row b is finished after
+                             // min(row_cap[b], max_new) sampled tokens; reset_search fills it with a huge value
 };
 struct RuleParams {
   int V, ldv, max_prompt, max_new;
@@ -326,7 +344,8 @@ void launch_self_attn_prefill(const T* qkv /*[n_seq*npos][3d]*/, T* kv_pool, con
 template <typename T>
 void launch_self_attn_decode(const T* qkv /*[B][3d]*/, T* kv_pool, const int32_t* page_table, int pages_per_seq,
                              int64_t pool_layer_off, int identity_pages, int row0, const int32_t* step, T* out /*[B][d]*/, int B, int H,
-                             hipStream_t s, SlabIn sq = SlabIn{} /*qkv from K-split partial tiles*/);
+                             hipStream_t s, SlabIn sq = SlabIn{} /*qkv from K-split partial tiles*/,
+                             const int32_t* done = nullptr /*[B] (already offset by row0): finished rows leave the kernel*/);
 template <typename T>
 void launch_copy_pages(T* pool, const int32_t* pairs_dev, int n_pairs, int n_layers, int H, int64_t layer_elems, hipStream_t s);
 template <typename T>
@@ -336,7 +355,10 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
                               SlabIn sq = SlabIn{} /*q from K-split partial tiles*/,
                               int ws_rows = 0 /*rows the workspace was sized for (0: B); rows that share a clip (kv_div 2..8)
                                                 are served by one K/V stream per clip when they fit*/,
-                              QProj qp = QProj{} /*W != nullptr: the query is projected inside the kernel (B * H >= 256, kv_div == 1)*/);
+                              QProj qp = QProj{} /*W != nullptr: the query is projected inside the kernel (B * H >= 256, kv_div == 1)*/,
+                              const int32_t* done = nullptr /*[B] device flags: rows with done[b] != 0 are FINISHED (EOT / token budget) and
+                                                              leave the kernel without streaming their cross-KV; their `out` rows keep
+                                                              the last live values.  nullptr: every row is live*/);
 // Signature of the kernel a launcher picked, in the spelling rocprofv3 prints ("name<template arguments> grid <threads>"):
 // recorded by the launchers of the measured kernels while g_kernel_sig_on is set (ttasr_bench_kernel), so that bench.py can tell
 // whether a committed counter profile still describes what the run launches.
@@ -344,7 +366,7 @@ void launch_cross_attn_decode(const T* q /*[B][d]*/, const T* K, const T* V /*[B
 template <typename T> void launch_xkv_quant(const T* src, uint8_t* dst, float* scale, int64_t n_blocks, int rows, hipStream_t s);
 template <typename T>
 bool launch_cross_attn_fp8(const T* q, const uint8_t* K8, const uint8_t* V8, const float* kscale, const float* vscale, T* out, int B, int H,
-                           int Tk, hipStream_t s, struct SlabIn sq);
+                           int Tk, hipStream_t s, struct SlabIn sq, const int32_t* done = nullptr);
 extern thread_local bool g_kernel_sig_on;
 extern thread_local char g_kernel_sig[192];
 template <typename T> inline const char* sig_type() { return sizeof(T) == 4 ? "float" : "unsigned short"; }

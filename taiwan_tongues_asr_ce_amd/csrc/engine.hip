@@ -34,7 +34,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
 
 extern "C" {
 
-const char* ttasr_version(void) { return "ttasr 0.3 (gfx950, HIP; f32 | bf16 | fp16)"; }
+const char* ttasr_version(void) { return "ttasr 0.4 (gfx950, HIP; f32 | bf16 | fp16)"; }
 
 const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -394,6 +394,18 @@ int ttasr_generate(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t
   if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
   if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
   return generate_rows(c, B, 1, prompt, prompt_len, max_prompt, o, 0.f, 0, out_tokens, out_len, out_lp, out_ns);
+  });
+}
+
+int ttasr_generate_capped(ttasr_ctx* c, int32_t B, const int32_t* prompt, const int32_t* prompt_len, int32_t max_prompt,
+                          const ttasr_gen_opts* o, const int32_t* row_max_new, int32_t* out_tokens, int32_t* out_len, float* out_lp,
+                          float* out_ns) {
+  return guarded(c, [&]() -> int {
+  TRY(check_ready(c, B));
+  if (!prompt || !prompt_len || !out_tokens || !out_len || !o || !row_max_new) return fail(c, TTASR_E_INVALID, "NULL argument");
+  if (B > c->B_enc) return fail(c, TTASR_E_INVALID, "encoder state holds %d clips, %d requested", c->B_enc, B);
+  if (max_prompt < 1 || max_prompt > c->max_prompt_alloc) return fail(c, TTASR_E_INVALID, "max_prompt %d", max_prompt);
+  return generate_rows(c, B, 1, prompt, prompt_len, max_prompt, o, 0.f, 0, out_tokens, out_len, out_lp, out_ns, row_max_new);
   });
 }
 

@@ -199,6 +199,9 @@ int build_workspaces(ttasr_ctx* c) {
   TRY(dalloc(c, &c->mask_dev, (size_t)c->V + 16));
   TRY(dalloc(c, &c->rule_dyn_dev, sizeof(RuleDyn)));
   c->st.dyn = c->rule_dyn_dev;
+  TRY(dalloc(c, &c->row_cap_dev, B * 4, false));
+  HIPCHK(c, hipMemsetAsync(c->row_cap_dev, 0x7f, B * 4, c->stream));
+  c->st.row_cap = c->row_cap_dev;
   TRY(dalloc(c, &c->pairs_dev, (size_t)B * 2 * 4));
   TRY(dalloc(c, &c->topk_lp, (size_t)B * 8 * 4)); TRY(dalloc(c, &c->topk_id, (size_t)B * 8 * 4));
   TRY(dalloc(c, &c->row_state, (size_t)B * 4 * 4));

@@ -110,6 +110,9 @@ struct ttasr_ctx {
                               // (K-split GEMMs), so 3 prompt positions x 32 clips cost 6.4 ms against 8.8 ms as three steps
   bool enc_res_epilogue = false;  // option enc_residual_epilogue: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
+  int32_t* row_cap_dev = nullptr;   // [maxB] per-row token budgets (st.row_cap; ttasr_generate_capped), "no budget" = 0x7f7f7f7f
+  bool ragged_exit = true;          // option ragged_exit [1]: finished rows (st.done) leave the attention kernels of the decode step
+                                    // (0: the static batch of rounds 1-5 - every row streams its cross-KV until the last one ends; A/B)
   RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
   int max_new_alloc = 0, max_prompt_alloc = 0;
@@ -249,7 +252,7 @@ int set_option(ttasr_ctx* c, const std::string& key, int v);
 int reset_search(ttasr_ctx* c, int B);
 int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt, const int32_t* prompt_len, int max_prompt,
                   const ttasr_gen_opts* o, float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp,
-                  float* out_ns);
+                  float* out_ns, const int32_t* row_cap = nullptr /*host [R] per-row token budgets, each in [1, max_new_tokens]*/);
 int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* prompt, int32_t max_prompt, const int32_t* plens,
                      const int32_t* sots, const ttasr_gen_opts* o, float patience, int32_t* out_tokens, int32_t* out_len,
                      float* out_lp, float* out_ns);

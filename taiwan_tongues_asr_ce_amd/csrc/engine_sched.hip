@@ -5,16 +5,28 @@
 namespace ttasr_detail {
 
 // ---- typed schedules ------------------------------------------------------------------------------
+// 256 x 256 tiles of a 16-bit GEMM (all its batches and groups)
+static int64_t gemm_tiles_256(const GemmArgs& g) {
+  return ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch) * std::max(1, g.groups);
+}
+// THE place that decides whether a 16-bit GEMM runs as persistent 256 x 256 workgroups (round 4): it pays once a workgroup has
+// several tiles to walk (>= 2 per CU).  Shared by gemm() and the grouped cross-KV launch of run_cross_kv, which used to carry
+// its own copy of this predicate.
+static bool gemm_takes_persistent(const ttasr_ctx* c, const GemmArgs& g) {
+  if (c->force_basic || g.M < 256) return false;
+  const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage, 4 = 3 as persistent workgroups
+  return (v ? v == 4 : (c->gemm_persistent && gemm_tiles_256(g) >= 512)) && gemm_bf16_v4_ok(g);
+}
+
 template <typename T>
 void gemm(ttasr_ctx* c, const GemmArgs& g) {
   if constexpr (sizeof(T) == 2) {
     if (!c->force_basic && g.M >= 256) {
-      const int v = c->gemm_force;  // option enc_gemm: force 1 = 128x128 two-stage, 2 = 256x128 three-stage, 3 = 256x256 four-stage, 4 = 3 as persistent workgroups
+      const int v = c->gemm_force;
       // 256x256 tiles need >= ~half the CUs' worth of tiles to pay; below that (one or two clips, short audio windows,
       // prefill) the 256x128 kernel's twice-as-many workgroups win (B = 1 encoder: 9.45 -> 6.6 ms)
-      const int64_t tiles_v3 = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * std::max(1, g.batch);
-      // persistent form (round 4): pays once a workgroup has several tiles to walk (>= 2 per CU)
-      if ((v ? v == 4 : (c->gemm_persistent && tiles_v3 >= 512)) && gemm_bf16_v4_ok(g)) {
+      const int64_t tiles_v3 = gemm_tiles_256(g);
+      if (gemm_takes_persistent(c, g)) {
         // round 5: the same persistent kernel with the last partial round of workgroups re-tiled into shorter tiles where that pays
         if (c->gemm_tail && v != 4 && launch_gemm_bf16_v5<T>(g, c->cur)) return;
         launch_gemm_bf16_v4<T>(g, c->cur);
@@ -72,10 +84,8 @@ int run_cross_kv(ttasr_ctx* c, int B) {
   bool grouped = false;
   if constexpr (sizeof(T) == 2) {
     GemmArgs g = layer_args(0);
-    const int64_t tiles = ((int64_t)(g.M + 255) / 256) * (g.N / 256) * L;
-    if (c->xkv_grouped && L > 1 && !c->force_basic && c->gemm_persistent && (c->gemm_force == 0 || c->gemm_force == 4) && g.M >= 256 &&
-        tiles >= 512 && gemm_bf16_v4_ok(g)) {
-      g.groups = L; g.group_stride_w = (int64_t)2 * d * d; g.group_stride_out = c->xkv_layer_elems;
+    g.groups = L; g.group_stride_w = (int64_t)2 * d * d; g.group_stride_out = c->xkv_layer_elems;
+    if (c->xkv_grouped && L > 1 && gemm_takes_persistent(c, g)) {
       launch_gemm_bf16_v4<T>(g, c->cur);
       grouped = true;
       enc_mark(c, EC_XKV);
@@ -196,6 +206,9 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   void *dh = tp(c->dh, d), *dqkv = tp(c->dqkv, 3 * d), *dq = tp(c->dq, d), *datt = tp(c->datt, d), *dmid = tp(c->dmid, ffn);
   float* logits = c->logits + (size_t)row0 * c->ldv;
   const bool skinny = sizeof(T) == 2 && !c->force_basic;
+  // round 6: rows whose search has FINISHED (st.done, set by select_kernel / uploaded by the beam search) leave the attention
+  // kernels of the step - the per-row cross-KV and self-KV streams are the bytes of a decode step that scale with the rows
+  const int32_t* done = c->ragged_exit ? c->st.done + row0 : nullptr;
   float* slab_base = c->slab;
   // K slices per GEMM kind (0 out-proj, 1 q, 2 qkv, 3 fc2); attention consumers sum at most 4 slabs
   auto slices = [&](int kind, int N, int K) {
@@ -258,7 +271,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
       if (!sqkv.n) { g.epi.bias = L.bqkv; g.epi.out_t = dqkv; dec_gemm<T>(c, g, L.wqkv_sh); } }
     if (!(c->skip_mask & 4))
       launch_self_attn_decode<T>((const T*)dqkv, (T*)c->pool, c->page_table, c->pages_per_seq, (int64_t)l * c->pool_layer_elems,
-                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s, sqkv);
+                                 c->identity_pages, row0, c->st.step, (T*)datt, n, c->H, s, sqkv, done);
     residual_gemm(datt, L.wo, L.wo_sh, L.bo, d, 0);
     ln(L.ln2g, L.ln2b);
     SlabIn sq;
@@ -273,12 +286,12 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
         const int64_t off = (int64_t)l * c->xkv_layer_elems + (int64_t)row0 * c->H * c->T * 64;
         const float* ksc = c->xkv8_scale + ((size_t)l * 2) * c->maxB * c->H + (size_t)row0 * c->H;
         fp8_done = launch_cross_attn_fp8<T>((const T*)dq, c->xkv8 + off, c->xkv8 + off + c->xkv_which_elems, ksc, ksc + (size_t)c->maxB * c->H,
-                                            (T*)datt, n, c->H, c->T, s, sq);
+                                            (T*)datt, n, c->H, c->T, s, sq, done);
       }
     }
     if (!fp8_done && !(c->skip_mask & 8))
       launch_cross_attn_decode<T>((const T*)dq, Kx, Kx + c->xkv_which_elems, (T*)datt, n, c->H, c->T, c->kv_div, s,
-                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq, c->maxB - row0);
+                                  c->no_xsplit ? nullptr : c->xsplit_ws + (size_t)row0 * c->H * 8 * 66, sq, c->maxB - row0, QProj{}, done);
     residual_gemm(datt, L.wox, L.wox_sh, L.box, d, 0);
     ln(L.ln3g, L.ln3b);
     { GemmArgs g = lin_args<T>(dh, L.w1, n, ffn, d); g.epi.bias = L.b1; g.epi.act = 1; g.epi.out_t = dmid; dec_gemm<T>(c, g, L.w1_sh); }
@@ -293,7 +306,7 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   if (mode != 1 && !(c->skip_mask & 16)) {
     DecState st = c->st;  // row-offset view of the search state
     st.cur_tok += row0; st.n_sampled += row0; st.last_tok += row0; st.pen_tok += row0; st.last_ts += row0; st.done += row0;
-    st.sum_logprob += row0; st.no_speech += row0; st.out_tokens += (size_t)row0 * c->rp.max_new;
+    st.sum_logprob += row0; st.no_speech += row0; st.out_tokens += (size_t)row0 * c->rp.max_new; st.row_cap += row0;
     if (st.prompt) { st.prompt += (size_t)row0 * c->rp.max_prompt; st.prompt_len += row0; }
     launch_select(logits, st, c->rp, n, nullptr, s, c->st.step + 1, total_rows);
   }

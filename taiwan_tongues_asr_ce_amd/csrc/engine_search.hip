@@ -88,6 +88,7 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
     c->xkv_fp8 = on; c->xkv8_valid = false;   // the e4m3 copy is (re)built by the next encode
   }
   else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
+  else if (key == "ragged_exit") c->ragged_exit = on;
   else return 1;
   g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0;
   drop_graphs(c);
@@ -105,13 +106,14 @@ int reset_search(ttasr_ctx* c, int B) {
   HIPCHK(c, hipMemsetAsync(c->st.n_done, 0, 16, s));
   HIPCHK(c, hipMemsetAsync(c->st.sum_logprob, 0, B * 4, s));
   HIPCHK(c, hipMemsetAsync(c->st.no_speech, 0, B * 4, s));
+  HIPCHK(c, hipMemsetAsync(c->row_cap_dev, 0x7f, B * 4, s));   // no per-row token budget (ttasr_generate_capped uploads its own)
   return 0;
 }
 
 // shared by ttasr_generate and ttasr_generate_sample: R rows, row r uses prompt (r / rows_per_clip)
 int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt, const int32_t* prompt_len, int max_prompt,
                   const ttasr_gen_opts* o, float temperature, uint32_t seed, int32_t* out_tokens, int32_t* out_len, float* out_lp,
-                  float* out_ns) {
+                  float* out_ns, const int32_t* row_cap) {
   int min_plen = 1 << 30, max_plen = 0;
   const int A = R / rows_per_clip;
   for (int a = 0; a < A; ++a) {
@@ -138,7 +140,17 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   HIPCHK(c, hipMemcpyAsync(c->prompt_dev, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemcpyAsync(c->plen_dev, pl.data(), R * 4, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipMemcpy2DAsync(c->st.cur_tok, 4, c->prompt_dev, (size_t)max_prompt * 4, 4, R, hipMemcpyDeviceToDevice, s));
-  HIPCHK(c, hipStreamSynchronize(s));  // pr / pl are stack temporaries
+  int max_cap = o->max_new_tokens;
+  if (row_cap) {   // per-row token budgets: row r is finished after min(row_cap[r], max_new_tokens) sampled tokens (or EOT)
+    max_cap = 1;
+    for (int r = 0; r < R; ++r) {
+      if (row_cap[r] < 1 || row_cap[r] > o->max_new_tokens)
+        return fail(c, TTASR_E_INVALID, "row_max_new[%d]=%d outside [1, max_new_tokens=%d]", r, row_cap[r], o->max_new_tokens);
+      max_cap = std::max(max_cap, (int)row_cap[r]);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->row_cap_dev, row_cap, (size_t)R * 4, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(c, hipStreamSynchronize(s));  // pr / pl (and the caller's row_cap) are read by the copies above
   c->st.prompt = c->prompt_dev; c->st.prompt_len = c->plen_dev;
   c->B_dec = R;
   c->kv_div = rows_per_clip;
@@ -146,7 +158,8 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   const int interval = std::max(1, o->check_interval);
   // exclusive; prompt + sampled tokens never exceed n_text_ctx (the reference's max_length = 448: the token sampled
   // from position n_text_ctx - 2 is the last one, position n_text_ctx - 1 is never fed)
-  const int last_step = std::min(c->cfg.n_text_ctx - 1, max_plen - 1 + o->max_new_tokens);
+  // (with per-row budgets no row samples past the largest of them: the loop ends there, no host poll needed to find out)
+  const int last_step = std::min(c->cfg.n_text_ctx - 1, max_plen - 1 + max_cap);
   hipEventRecord(c->ev[5], s);
   // A prefill pass runs the encoder-side GEMM kernels on rows x positions; for a handful of positions that costs more
   // than the decode steps it replaces (measured at large-v3, 3 positions x 32 rows: +5 ms), so the
@@ -184,6 +197,7 @@ int generate_rows(ttasr_ctx* c, int R, int rows_per_clip, const int32_t* prompt,
   HIPCHK(c, hipMemcpyAsync(out_len, c->st.n_sampled, R * 4, hipMemcpyDeviceToHost, s));
   if (out_lp) HIPCHK(c, hipMemcpyAsync(out_lp, c->st.sum_logprob, R * 4, hipMemcpyDeviceToHost, s));
   if (out_ns) HIPCHK(c, hipMemcpyAsync(out_ns, c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipMemsetAsync(c->st.done, 0, (size_t)R * 4, s));   // the flags belong to THIS search: later step-API calls see live rows
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);
@@ -243,6 +257,8 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
   rebuild_free(-1);
   for (int r = 0; r < R; ++r) cur_tok[r] = prompt[(size_t)(r / beam) * max_prompt];
   std::vector<char> done(A, 0);
+  std::vector<int32_t> done_rows(R, 0);   // device copy of `done`, one flag per row: finished clips leave the attention kernels (round 6)
+  bool done_dirty = false;
   std::vector<float> ns_final(A, 0.f);
   hipEventRecord(c->ev[5], s);
   // Batched prompt prefill: the beam rows of a clip share one prompt, so its positions are computed ONCE per clip
@@ -296,6 +312,7 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
       for (auto& v : up) if (v < 0) v = 0;
       HIPCHK(c, hipMemcpyAsync(c->page_table, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
       HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, cur_tok.data(), R * 4, hipMemcpyHostToDevice, s));
+      if (done_dirty) { HIPCHK(c, hipMemcpyAsync(c->st.done, done_rows.data(), (size_t)R * 4, hipMemcpyHostToDevice, s)); done_dirty = false; }
       HIPCHK(c, hipStreamSynchronize(s));  // `up` is a stack temporary
     }
     // 2. one decoder step over the R rows (logits only; the search itself runs on the host)
@@ -372,7 +389,10 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
     bool all_done = true;
     for (int a = 0; a < A; ++a) {
       const bool searching = !done[a] && pos + 1 >= plens[a];
-      if (searching && ((int)finished[a].size() >= max_cand || (int)seqs[a * beam].size() >= max_new)) done[a] = 1;
+      if (searching && ((int)finished[a].size() >= max_cand || (int)seqs[a * beam].size() >= max_new)) {
+        done[a] = 1; done_dirty = true;
+        for (int b = 0; b < beam; ++b) done_rows[a * beam + b] = 1;
+      }
       for (int b = 0; b < beam; ++b) {
         const int r = a * beam + b;
         cur_tok[r] = done[a] ? o->eot : (searching ? seqs[r].back() : forced_next(a));
@@ -382,6 +402,7 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
     if (all_done) stop = true;
   }
   hipEventRecord(c->ev[6], s);
+  HIPCHK(c, hipMemsetAsync(c->st.done, 0, (size_t)R * 4, s));   // the flags belong to THIS search
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
   hipEventElapsedTime(&c->phase_ms[3], c->ev[5], c->ev[6]);

@@ -180,20 +180,22 @@ using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
 template <typename T, int MODE, bool SLAB, bool IDENT>
 __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* pool, const int32_t* page_table,
                                                                int pages_per_seq, int identity_pages, int row0,
-                                                               const int32_t* step, T* out, int H, int npos, SlabIn sq) {
+                                                               const int32_t* step, T* out, const int32_t* done, int H, int npos,
+                                                               SlabIn sq) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;  // rows per wave-instruction
   constexpr int UNROLL = 4;
   __shared__ float part[4][64];
   __shared__ float red[4][2];
   // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin)
   qkv = sgpr_pin_ptr(qkv); pool = sgpr_pin_ptr(pool); page_table = sgpr_pin_ptr(page_table); step = sgpr_pin_ptr(step);
-  out = sgpr_pin_ptr(out);
+  out = sgpr_pin_ptr(out); done = sgpr_pin_ptr(done);
   pages_per_seq = sgpr_pin(pages_per_seq); identity_pages = sgpr_pin(identity_pages); row0 = sgpr_pin(row0); H = sgpr_pin(H);
   npos = sgpr_pin(npos);
   sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
   sq.ld = sgpr_pin(sq.ld);
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64, pos = MODE == 0 ? *step : b % npos;
+  const int done_raw = row_done_issue(done, b, pool);   // scalar load, in flight under the vector loads below (see row_done_exit)
   const T* qp = qkv + (int64_t)b * 3 * d + h * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   // global row: qkv / out are already offset to the half-batch, the KV pages are not
@@ -235,6 +237,10 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
     RowVec<T>::load(qp + d + sub * VEC, kn);
     RowVec<T>::load(qp + 2 * d + sub * VEC, vn);
   }
+  // Round 6: a FINISHED row of the batch (select_kernel set done[b] at an earlier step: EOT sampled, or the row's token budget
+  // reached) leaves the kernel here - nothing appended, nothing attended, `out` keeps the row's last live values.  Rows are
+  // computed independently of their neighbours everywhere in the decode step, so the live rows' bits do not change.
+  if (MODE == 0 && done && done_raw) { if (npos < 0) red[0][0] = kv[0][0] + vv[0][0] + q[0]; return; }   // (never-taken store: row_done_exit)
   if (MODE != 2 && wave == 0 && rin == 0) {  // append this step's k, v
     const int page = page_of(pos);
     T* kdst = pool + ((((int64_t)page * 2 + 0) * H + h) * PAGE + (pos % PAGE)) * 64;
@@ -305,11 +311,12 @@ __global__ __launch_bounds__(256) void self_attn_decode_kernel(const T* qkv, T* 
 }
 template <typename T>
 void launch_self_attn_decode(const T* qkv, T* kv_pool, const int32_t* page_table, int pages_per_seq, int64_t pool_layer_off,
-                             int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s, SlabIn sq) {
+                             int identity_pages, int row0, const int32_t* step, T* out, int B, int H, hipStream_t s, SlabIn sq,
+                             const int32_t* done) {
   // identity_pages: greedy decoding never re-indexes the table, so the page id is computed, not loaded
 #define TTASR_SA(SLAB_, IDENT_)                                                                                              \
   hipLaunchKernelGGL((self_attn_decode_kernel<T, 0, SLAB_, IDENT_>), dim3(H, B), dim3(256), 0, s, qkv, kv_pool + pool_layer_off, \
-                     page_table, pages_per_seq, identity_pages, row0, step, out, H, 1, sq)
+                     page_table, pages_per_seq, identity_pages, row0, step, out, done, H, 1, sq)
   if (sq.n > 0) { if (identity_pages) TTASR_SA(true, true); else TTASR_SA(true, false); }
   else { if (identity_pages) TTASR_SA(false, true); else TTASR_SA(false, false); }
 #undef TTASR_SA
@@ -320,7 +327,8 @@ void launch_self_attn_prefill(const T* qkv, T* kv_pool, const int32_t* page_tabl
                               int identity_pages, T* out, int n_seq, int npos, int H, hipStream_t s) {
 #define TTASR_SP(MODE_, IDENT_)                                                                                                 \
   hipLaunchKernelGGL((self_attn_decode_kernel<T, MODE_, false, IDENT_>), dim3(H, n_seq * npos), dim3(256), 0, s, qkv,          \
-                     kv_pool + pool_layer_off, page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out, H, npos, SlabIn{})
+                     kv_pool + pool_layer_off, page_table, pages_per_seq, identity_pages, 0, (const int32_t*)nullptr, out,          \
+                     (const int32_t*)nullptr, H, npos, SlabIn{})
   if (identity_pages) { TTASR_SP(1, true); TTASR_SP(2, true); } else { TTASR_SP(1, false); TTASR_SP(2, false); }
 #undef TTASR_SP
 }
@@ -349,11 +357,11 @@ template void launch_copy_pages<float>(float*, const int32_t*, int, int, int, in
 template void launch_copy_pages<bf16_t>(bf16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_copy_pages<f16_t>(f16_t*, const int32_t*, int, int, int, int64_t, hipStream_t);
 template void launch_self_attn_decode<float>(const float*, float*, const int32_t*, int, int64_t, int, int, const int32_t*, float*,
-                                             int, int, hipStream_t, SlabIn);
+                                             int, int, hipStream_t, SlabIn, const int32_t*);
 template void launch_self_attn_decode<bf16_t>(const bf16_t*, bf16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
-                                              bf16_t*, int, int, hipStream_t, SlabIn);
+                                              bf16_t*, int, int, hipStream_t, SlabIn, const int32_t*);
 template void launch_self_attn_decode<f16_t>(const f16_t*, f16_t*, const int32_t*, int, int64_t, int, int, const int32_t*,
-                                              f16_t*, int, int, hipStream_t, SlabIn);
+                                              f16_t*, int, int, hipStream_t, SlabIn, const int32_t*);
 
 // ------------------------------------------------------------------------------------------------
 // decoder cross-attention.  K, V: [B][H][Tk][64] (head-major, written by the cross-KV GEMM epilogue), so
@@ -380,12 +388,13 @@ template <typename T, bool NT> __device__ __forceinline__ void load_row(const T*
 // VERDICT r3 next #1c) computed HERE from the LayerNorm output rows and this head's 64 rows of Wq behind the first K batch
 // (one launch less per layer; every workgroup re-reads its head's 164 KB of Wq through L2: measured in DESIGN.md 4.11).
 template <typename T, bool PROBS, int NWV, int UNROLL, bool NT, int QMODE>
-__global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q, const T* K, const T* V, T* out, int H, int Tk,
-                                                                     int kv_div, const int* sel, float* probs, SlabIn sq, QProj qp) {
+__global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q, const T* K, const T* V, T* out, const int32_t* done,
+                                                                     int H, int Tk, int kv_div, const int* sel, float* probs, SlabIn sq,
+                                                                     QProj qp) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
   // every kernel argument fetched in ONE batch at entry (common.hpp sgpr_pin): the K stream starts one round trip after launch
-  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out);
+  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out); done = sgpr_pin_ptr(done);
   H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div);
   if constexpr (PROBS) { sel = sgpr_pin_ptr(sel); probs = sgpr_pin_ptr(probs); }
   sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   float* part = sc + Tk;          // [NWV][64]
   float* red = part + NWV * 64;   // [2 * NWV]
   const int bk = kv_div == 1 ? b : b / kv_div;  // beam search: the kv_div rows of one clip share its cross-KV (never replicated)
+  const int done_raw = row_done_issue(done, b, K);   // finished row of the batch: see row_done_exit below
   const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64;
   const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64;
   float mloc = -1e30f;
@@ -455,6 +465,7 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
   }
 #endif
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  if (!PROBS && done && done_raw) { if (Tk < 0) sc[0] = kv[0][0] + kv[UNROLL - 1][0] + qv[0]; return; }   // row_done_exit (see cross_attn_pipe_kernel)
   for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
     if (it0 > 0) load_k(it0);
 #pragma unroll
@@ -547,12 +558,12 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
 // form runs 6.42-6.48 TB/s: the gain at B = 32 is a shorter tail of the uneven 3-vs-2 workgroup split, not a faster stream.
 // 16-bit storage, 4 waves, decode step only (no PROBS).
 template <typename T, bool NT, bool QSLAB, int U>
-__global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const T* K, const T* V, T* out, int H, int Tk, int kv_div,
-                                                              SlabIn sq) {
+__global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const T* K, const T* V, T* out, const int32_t* done, int H,
+                                                              int Tk, int kv_div, SlabIn sq) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int VEC = 8, LPR = 8, RPI = 8, NWV = 4;
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
-  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out);
+  q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out); done = sgpr_pin_ptr(done);
   H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div);
   sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
   sq.ld = sgpr_pin(sq.ld);
@@ -562,6 +573,10 @@ __global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const 
   float* part = sc + Tk;
   float* red = part + NWV * 64;
   const int bk = kv_div == 1 ? b : b / kv_div;
+  // Round 6: done[b] != 0 = row b of the decode batch is FINISHED (select_kernel set it at an earlier step:
+  // EOT sampled, or the row's token budget reached).  One scalar load, requested here and first needed after the query is in
+  // (row_done_exit below): a live row pays nothing for it.
+  const int done_raw = row_done_issue(done, b, K);
   const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
   const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
   const int n_it = (Tk + NWV * RPI - 1) / (NWV * RPI);
@@ -583,6 +598,15 @@ __global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const 
   float qv[VEC];
   if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
+  // row_done_exit: a finished row leaves HERE - workgroup-uniform, before the second K batch is requested - and takes its
+  // 2 * Tk * 128 B of cross-KV (384 KB per (row, head) and layer at large-v3: 78 % of a decode step's bytes are these per-ROW
+  // streams) out of the step; `out` keeps the row's last live values (finite; select_kernel ignores a finished row's logits).
+  // The grid, and with it every captured graph, is unchanged, and no live row's arithmetic depends on a neighbour: the live
+  // rows' outputs are bit-identical to the static batch's.  The exit sits AFTER the first K batch and the query were requested
+  // so that a live row waits for nothing new (a finished row wastes that one batch: 3 of the 3 000 rows per lane pair); the
+  // never-taken store (Tk < 0 is unknown to the compiler) keeps a use of the batch on this side of the branch, without which
+  // the optimiser sinks the loads BELOW it - behind the wait for done[b].
+  if (done && done_raw) { if (Tk < 0) sc[0] = __uint_as_float(ra[0].x ^ ra[U - 1].x) + qv[0]; return; }
   float mloc = -1e30f;
   auto score = [&](int it0, const u32x4_t (&r)[U]) {
 #pragma unroll
@@ -676,7 +700,7 @@ __global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const 
 template <typename T>
 __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restrict__ q, const T* __restrict__ K,
                                                                const T* __restrict__ V, int H, int Tk, int kv_div, int chunk,
-                                                               float* __restrict__ ws, SlabIn sq) {
+                                                               float* __restrict__ ws, SlabIn sq, const int32_t* __restrict__ done) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = 8;
   extern __shared__ float sc[];  // [chunk] scores, then [4][64] partial outputs, [8] reductions
@@ -686,6 +710,7 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + chunk;
   float* red = part + 4 * 64;
+  if (done && sload_i32(done + b)) return;   // finished row of the batch (round 6): its slices are not computed, the merge kernel skips it too
   float qv[VEC];
   if (sq.n > 0) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
   else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
@@ -766,8 +791,10 @@ __global__ __launch_bounds__(256) void cross_attn_split_kernel(const T* __restri
 
 // merge of the slices: one wave per (b, h)
 template <typename T>
-__global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __restrict__ ws, T* __restrict__ out, int H, int S) {
+__global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __restrict__ ws, T* __restrict__ out, int H, int S,
+                                                              const int32_t* __restrict__ done) {
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x;
+  if (done && sload_i32(done + b)) return;   // finished row: no slices were written for it this step; `out` keeps its last live values
   const float* all = ws + ((int64_t)b * H + h) * S * 66;
   float m[8], l[8], a[8];
 #pragma unroll
@@ -801,7 +828,8 @@ __global__ __launch_bounds__(64) void cross_attn_merge_kernel(const float* __res
 template <typename T, int NQ>
 __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict__ q, const T* __restrict__ K, const T* __restrict__ V,
                                                             int H, int Tk, int chunk, float* __restrict__ ws, SlabIn sq,
-                                                            int kv_div, int groups, int nq_last, T* __restrict__ out) {
+                                                            int kv_div, int groups, int nq_last, T* __restrict__ out,
+                                                            const int32_t* __restrict__ done) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
   constexpr int UNROLL = NQ <= 4 ? 8 : 4;
   extern __shared__ float sc[];  // [NQ][chunk] scores, then [4][NQ][64] partial outputs, [2][NQ][4] reductions
@@ -814,6 +842,11 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + NQ * chunk;
   float* red = part + 4 * NQ * 64;
+  if (done) {   // round 6: a group whose rows are ALL finished (a finished clip of a beam search, sampled rows that all ended)
+    int all = 1;   // streams nothing; a partly finished group is computed whole (its finished rows' results are ignored)
+    for (int qi = 0; qi < nq; ++qi) all &= sload_i32(done + row0 + qi) != 0;
+    if (all) return;
+  }
   const int t0 = z * chunk, n = min(chunk, Tk - t0);  // this slice: frames t0 .. t0+n-1 (n >= 1 by construction)
   const T* Kp = K + (((int64_t)clip * H + h) * Tk + t0) * 64;
   const T* Vp = V + (((int64_t)clip * H + h) * Tk + t0) * 64;
@@ -938,7 +971,7 @@ int cross_attn_splits(int B, int H, int Tk) {
 
 template <typename T>
 void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B, int H, int Tk, int kv_div, hipStream_t s,
-                              float* split_ws, SlabIn sq, int ws_rows, QProj qp) {
+                              float* split_ws, SlabIn sq, int ws_rows, QProj qp, const int32_t* done) {
   if (ws_rows <= 0) ws_rows = B;
   if (qp.W) split_ws = nullptr;   // in-kernel q projection (lab builds): the single-pass per-row kernel only (B * H >= 256, kv_div == 1)  // the workspace holds ws_rows rows x 8 slices x H heads x 66 floats
   // many rows per clip (a long previous-text prompt in one prefill pass): the rows are the M dimension of an MFMA flash pass over
@@ -964,13 +997,13 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
     if (lds <= 64 * 1024 && ws_ok) {
       const dim3 grid(H, A * groups, S2);
 #define TTASR_MQ(NQ_) \
-  hipLaunchKernelGGL((cross_attn_mq_kernel<T, NQ_>), grid, dim3(256), lds, s, q, K, V, H, Tk, chunk, split_ws, sq, kv_div, groups, nq_last, out)
+  hipLaunchKernelGGL((cross_attn_mq_kernel<T, NQ_>), grid, dim3(256), lds, s, q, K, V, H, Tk, chunk, split_ws, sq, kv_div, groups, nq_last, out, done)
       switch (NQ) {
         case 2: TTASR_MQ(2); break; case 3: TTASR_MQ(3); break; case 4: TTASR_MQ(4); break; case 5: TTASR_MQ(5); break;
         case 6: TTASR_MQ(6); break; case 7: TTASR_MQ(7); break; default: TTASR_MQ(8); break;
       }
 #undef TTASR_MQ
-      if (S2 > 1) hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
+      if (S2 > 1) hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2, done);
       return;
     }
   }
@@ -979,8 +1012,8 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
     int chunk = ((Tk + S - 1) / S + 31) / 32 * 32;
     const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty
     size_t lds = sizeof(float) * (chunk + 4 * 64 + 8);
-    hipLaunchKernelGGL(cross_attn_split_kernel<T>, dim3(H, B, S2), dim3(256), lds, s, q, K, V, H, Tk, kv_div, chunk, split_ws, sq);
-    hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2);
+    hipLaunchKernelGGL(cross_attn_split_kernel<T>, dim3(H, B, S2), dim3(256), lds, s, q, K, V, H, Tk, kv_div, chunk, split_ws, sq, done);
+    hipLaunchKernelGGL(cross_attn_merge_kernel<T>, dim3(H, B), dim3(64), 0, s, split_ws, out, H, S2, done);
     return;
   }
   // g_xattn_variant (option xattn_nontemporal, A/B testing): 1 = nontemporal K/V loads (default), 0 = plain.  (16 rows in flight per lane and
@@ -990,7 +1023,7 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
 #define TTASR_XA_QPROJ(NT_)                                                                                                            \
   if constexpr (sizeof(T) == 2) {                                                                                                      \
     if (qp.W) {                                                                                                                        \
-      hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 2>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,       \
+      hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 2>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, H, Tk, \
                          kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                                        \
       return;                                                                                                                          \
     }                                                                                                                                  \
@@ -1001,14 +1034,14 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
 #define TTASR_XA(NT_)                                                                                                                  \
   do {                                                                                                                                 \
     TTASR_XA_QPROJ(NT_)                                                                                                                \
-    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 1>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, \
-                                     Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                        \
-    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 0>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk,  \
-                            kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                                     \
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 1>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, \
+                                     H, Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                     \
+    else hipLaunchKernelGGL((cross_attn_decode_kernel<T, false, 4, 8, NT_, 0>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, H, \
+                            Tk, kv_div, (const int*)nullptr, (float*)nullptr, sq, qp);                                                 \
   } while (0)
   if constexpr (sizeof(T) == 2) {
     if ((g_xattn_variant & 2) && !qp.W) {   // software-pipelined form (default since round 4), 3 rows per lane and batch
-#define TTASR_XP(NT_, QS_) hipLaunchKernelGGL((cross_attn_pipe_kernel<T, NT_, QS_, 3>), dim3(H, B), dim3(256), lds, s, q, K, V, out, H, Tk, kv_div, sq)
+#define TTASR_XP(NT_, QS_) hipLaunchKernelGGL((cross_attn_pipe_kernel<T, NT_, QS_, 3>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, H, Tk, kv_div, sq)
       const bool nt = g_xattn_variant & 1, qs = sq.n > 0;
       if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "cross_attn_pipe_kernel<%s, %s, %s, 3> grid %d", sig_type<T>(),
                                     nt ? "true" : "false", qs ? "true" : "false", H * B * 256);
@@ -1027,7 +1060,7 @@ template <typename T>
 void launch_cross_attn_probs(const T* q, const T* K, const T* V, T* out, int rows, int H, int Tk, const int* sel, float* probs,
                              hipStream_t s) {
   size_t lds = sizeof(float) * (Tk + 4 * 64 + 8);
-  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false, 0>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, H, Tk, rows, sel, probs, SlabIn{}, QProj{});
+  hipLaunchKernelGGL((cross_attn_decode_kernel<T, true, 4, 8, false, 0>), dim3(H, rows), dim3(256), lds, s, q, K, V, out, (const int32_t*)nullptr, H, Tk, rows, sel, probs, SlabIn{}, QProj{});
 }
 template void launch_cross_attn_probs<float>(const float*, const float*, const float*, float*, int, int, int, const int*, float*,
                                              hipStream_t);
@@ -1036,8 +1069,8 @@ template void launch_cross_attn_probs<bf16_t>(const bf16_t*, const bf16_t*, cons
 template void launch_cross_attn_probs<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, const int*, float*,
                                               hipStream_t);
 template void launch_cross_attn_decode<float>(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t, float*,
-                                              SlabIn, int, QProj);
+                                              SlabIn, int, QProj, const int32_t*);
 template void launch_cross_attn_decode<bf16_t>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, int, hipStream_t,
-                                               float*, SlabIn, int, QProj);
+                                               float*, SlabIn, int, QProj, const int32_t*);
 template void launch_cross_attn_decode<f16_t>(const f16_t*, const f16_t*, const f16_t*, f16_t*, int, int, int, int, hipStream_t,
-                                               float*, SlabIn, int, QProj);
+                                               float*, SlabIn, int, QProj, const int32_t*);

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
   st.done = sgpr_pin_ptr(st.done); st.n_done = sgpr_pin_ptr(st.n_done); st.sum_logprob = sgpr_pin_ptr(st.sum_logprob);
   st.no_speech = sgpr_pin_ptr(st.no_speech); st.out_tokens = sgpr_pin_ptr(st.out_tokens); st.prompt = sgpr_pin_ptr(st.prompt);
   st.prompt_len = sgpr_pin_ptr(st.prompt_len); st.mask = sgpr_pin_ptr(st.mask); st.dyn = sgpr_pin_ptr(st.dyn);
+  st.row_cap = sgpr_pin_ptr(st.row_cap);
   p.V = sgpr_pin(p.V); p.ldv = sgpr_pin(p.ldv);
   p.eot = sgpr_pin(p.eot); p.no_timestamps = sgpr_pin(p.no_timestamps); p.timestamp_begin = sgpr_pin(p.timestamp_begin);
   p.no_speech = sgpr_pin(p.no_speech); p.timestamps = sgpr_pin(p.timestamps);
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
   r.n = st.n_sampled[b];
   const int last = st.last_tok[b], pen = st.pen_tok[b], lts = st.last_ts[b], done_b = st.done[b];
   const float slp = st.sum_logprob[b];
+  const int cap_b = st.row_cap[b];   // this row's token budget (ttasr_generate_capped; otherwise huge)
   const RuleDyn dyn = *st.dyn;  // the per-window rule scalars (the by-value copies in `p` are those of the capture)
   __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first use below
   p.max_prompt = dyn.max_prompt; p.max_new = dyn.max_new; p.sot_index = dyn.sot_index; p.seed = dyn.seed;
@@ -329,7 +331,9 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* logits, DecSt
     st.pen_tok[b] = last;
     st.last_tok[b] = choice;
     if (choice >= tb && p.timestamps) st.last_ts[b] = choice;
-    if (choice == p.eot || r.n + 1 >= p.max_new) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
+    // finished: EOT, the call's token budget, or this row's own (round 6).  From the NEXT step on the attention kernels skip the
+    // row (done[b]: kernels_attn.hip row_done_exit) and the `done_b` branch above feeds it EOT without touching its state.
+    if (choice == p.eot || r.n + 1 >= min(p.max_new, cap_b)) { st.done[b] = 1; atomicAdd(st.n_done, 1); }
   }
   if (tid == 0) step_ticket(ticket, total_rows, st.step, step);
   if constexpr (HOOK) {  // known-answer hook: the forced-timestamp branch also masks the text range

