@@ -387,6 +387,7 @@ def main():
     import torch.distributed as dist
     from taiwan_tongues_asr_ce_amd import synth
     from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, PRESETS
+    from taiwan_tongues_asr_ce_amd import dist as _dist_mod
     from taiwan_tongues_asr_ce_amd.dist import barrier as dist_barrier, broadcast_weights, gather_tokens, init_process_group
     from taiwan_tongues_asr_ce_amd.engine import Engine
 
@@ -661,6 +662,7 @@ def main():
                        "parallelism": f"dp{world}" + (f" x {C_} contexts" if C_ > 1 else "") +
                                       (" (ranks share GPUs over gloo: plumbing check, not a scaling number)"
                                        if world > torch.cuda.device_count() else ""),
+                       "host_binding": (_dist_mod.HOST_BINDING or None) if world > 1 else None,
                        "rank_logits_spread": logits_spread,
                        "rank_ms_per_step": None if rank_ms is None else {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2),
                                                                           "per_rank": [round(x, 2) for x in rank_ms]},

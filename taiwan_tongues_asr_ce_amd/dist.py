@@ -22,11 +22,97 @@ def force_collectives() -> bool:
     return os.environ.get("TTASR_DIST_FORCE", "") not in ("", "0")
 
 
+def resolve_backend(requested: Optional[str], local_world: int, n_devices: int, cuda: bool) -> Tuple[str, Optional[str]]:
+    """(backend, note) for a group of `local_world` ranks on this node seeing `n_devices` GPUs.  RCCL refuses two ranks on one
+    device ("ncclInvalidUsage: Duplicate GPU detected" - what `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` died
+    with on a 1-GPU box in round 5): ranks > devices talk over gloo and the note says so (a plumbing run, never a scaling
+    number); an EXPLICIT request for nccl in that situation is a one-line error instead of RCCL's."""
+    want = requested or os.environ.get("TTASR_DIST_BACKEND") or ("nccl" if cuda else "gloo")
+    if want == "nccl" and cuda and local_world > n_devices:
+        if requested == "nccl" or os.environ.get("TTASR_DIST_BACKEND") == "nccl":
+            raise RuntimeError(f"{local_world} ranks on this node but {n_devices} visible GPU(s): RCCL needs one device per rank "
+                               "(use TTASR_DIST_BACKEND=gloo for a shared-GPU plumbing run)")
+        return "gloo", (f"{local_world} ranks share {n_devices} GPU(s): RCCL refuses two ranks per device, so the group runs over "
+                        "gloo - plumbing only, not a scaling measurement")
+    return want, None
+
+
+def host_thread_plan(local_world: int, n_cpus: int) -> int:
+    """Host threads per rank for torch / OpenMP work when `local_world` ranks share a host: every rank drives a ~45 000-launch
+    decode chain per step from ONE thread and must not be crowded out by 8 x (all cores) OpenMP pools (risk
+    (ii)).  An equal share of the cores, at least 1, at most 32 (torch's small ops get slower beyond that: conftest.py)."""
+    return max(1, min(32, n_cpus // max(1, local_world)))
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_of_pci(pci_bdf: str, sysfs: str = "/sys") -> Optional[List[int]]:
+    """CPUs of the NUMA node the PCI device `pci_bdf` ("0000:c1:00.0") hangs off, from sysfs; None when the kernel reports no
+    node (-1: single-socket / virtualised hosts) or the files are missing."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bdf, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
+def bind_rank_to_gpu_numa(local: int, local_world: int, sysfs: str = "/sys", pci_bdf: Optional[str] = None) -> dict:
+    """Several ranks on one host (world > 1): cap this rank's torch / OpenMP threads at its share of the cores and bind the
+    calling (= kernel-launching) thread to the CPUs of the NUMA node of its GPU, so that eight launch threads neither migrate
+    across sockets nor fight eight full-size OpenMP pools.  Best effort, never fatal; returns what was done (bench.py prints it in
+    config.host_binding).  `pci_bdf` (tests) overrides the lookup through torch.cuda.get_device_properties."""
+    info: dict = {"threads": None, "numa_cpus": None}
+    n_cpus = os.cpu_count() or 1
+    threads = host_thread_plan(local_world, n_cpus)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    try:
+        torch.set_num_threads(min(threads, int(os.environ["OMP_NUM_THREADS"])))
+        info["threads"] = torch.get_num_threads()
+    except Exception as ex:   # pragma: no cover
+        info["threads_error"] = str(ex)
+    try:
+        if pci_bdf is None and torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(local)
+            pci_bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        cpus = numa_cpus_of_pci(pci_bdf, sysfs) if pci_bdf else None
+        if cpus and hasattr(os, "sched_setaffinity"):
+            allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+                info["numa_cpus"] = len(allowed)
+                info["pci"] = pci_bdf
+    except Exception as ex:
+        info["numa_error"] = str(ex)
+    return info
+
+
+HOST_BINDING: dict = {}     # what init_process_group did for this rank (bench.py: config.host_binding)
+BACKEND_NOTE: Optional[str] = None
+
+
 def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; no-op for a single process unless force_collectives()."""
+    global BACKEND_NOTE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and not HOST_BINDING:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        HOST_BINDING.update(bind_rank_to_gpu_numa(local % max(n_dev, 1), local_world))
     if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -38,9 +124,13 @@ def init_process_group(backend: Optional[str] = None) -> Tuple[int, int, int]:
             s.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(s.getsockname()[1])
             s.close()
-        if backend is None:
-            # TTASR_DIST_BACKEND=gloo: plumbing smoke test with several ranks sharing one GPU (RCCL refuses that)
-            backend = os.environ.get("TTASR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # TTASR_DIST_BACKEND=gloo: plumbing smoke test with several ranks sharing one GPU; ranks > visible devices fall back to it
+        # by themselves (resolve_backend) - whatever launcher started them
+        cuda = torch.cuda.is_available()
+        backend, BACKEND_NOTE = resolve_backend(backend, local_world, torch.cuda.device_count() if cuda else 0, cuda)
+        if BACKEND_NOTE and rank == 0:
+            import sys
+            print(f"[ttasr.dist] {BACKEND_NOTE}", file=sys.stderr, flush=True)
         kw = {}
         if backend == "nccl":
             local = local % max(torch.cuda.device_count(), 1)

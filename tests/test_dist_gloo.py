@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 
@@ -298,3 +299,57 @@ def test_bench_launcher_stops_the_other_ranks_when_one_dies(tmp_path, capsys):
     rc = bench._self_launch(3, cmd=[sys.executable, str(script), "ok"])
     out = capsys.readouterr().out
     assert rc == 0 and out.strip() == '{"value": 1}'
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 6: first-contact hardening that needs no hardware.
+def test_ranks_beyond_the_visible_devices_fall_back_to_gloo_or_fail_in_one_line(monkeypatch):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` on a 1-GPU box died inside RCCL with
+    "ncclInvalidUsage: Duplicate GPU detected" (gpurun_out/last/gpus2.err, round 5): the fallback lived only in bench.py's own
+    launcher.  Now every launcher goes through dist.resolve_backend."""
+    from taiwan_tongues_asr_ce_amd import dist as D
+    monkeypatch.delenv("TTASR_DIST_BACKEND", raising=False)
+    assert D.resolve_backend(None, 8, 8, True) == ("nccl", None)                  # one device per rank: RCCL
+    be, note = D.resolve_backend(None, 2, 1, True)                                # two ranks, one GPU: gloo, and the line says so
+    assert be == "gloo" and "plumbing" in note and "2 ranks share 1 GPU" in note
+    assert D.resolve_backend(None, 2, 0, False) == ("gloo", None)                 # no GPU at all (this container)
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        D.resolve_backend("nccl", 2, 1, True)                                     # explicit request: a one-line error, not RCCL's
+    monkeypatch.setenv("TTASR_DIST_BACKEND", "nccl")
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        D.resolve_backend(None, 4, 2, True)
+    monkeypatch.setenv("TTASR_DIST_BACKEND", "gloo")
+    assert D.resolve_backend(None, 2, 8, True) == ("gloo", None)
+
+
+def test_host_thread_share_and_numa_binding_from_a_fake_sysfs(tmp_path, monkeypatch):
+    """Eight ranks on one host: each caps its torch / OpenMP pool at its share of the cores and binds its launch thread to the
+    NUMA node of its GPU (sysfs lookup by PCI address) - DESIGN section 5, risk (ii)."""
+    import os
+    import torch
+    from taiwan_tongues_asr_ce_amd import dist as D
+    assert D.host_thread_plan(8, 256) == 32 and D.host_thread_plan(8, 64) == 8 and D.host_thread_plan(8, 4) == 1
+    assert D.host_thread_plan(1, 256) == 32 and D.host_thread_plan(2, 8) == 4
+    assert D._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    bdf = "0000:c1:00.0"
+    (tmp_path / "bus" / "pci" / "devices" / bdf).mkdir(parents=True)
+    (tmp_path / "bus" / "pci" / "devices" / bdf / "numa_node").write_text("1\n")
+    (tmp_path / "devices" / "system" / "node" / "node1").mkdir(parents=True)
+    mine = sorted(os.sched_getaffinity(0))
+    (tmp_path / "devices" / "system" / "node" / "node1" / "cpulist").write_text(f"{mine[0]}-{mine[0]},{mine[-1]},4000-4001\n")
+    assert D.numa_cpus_of_pci(bdf, str(tmp_path))[:1] == [mine[0]]
+    assert D.numa_cpus_of_pci("0000:00:00.0", str(tmp_path)) is None              # unknown device
+    (tmp_path / "bus" / "pci" / "devices" / bdf / "numa_node").write_text("-1\n")
+    assert D.numa_cpus_of_pci(bdf, str(tmp_path)) is None                         # the kernel reports no node
+    (tmp_path / "bus" / "pci" / "devices" / bdf / "numa_node").write_text("1\n")
+    before_threads, before_aff = torch.get_num_threads(), os.sched_getaffinity(0)
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    try:
+        info = D.bind_rank_to_gpu_numa(0, 2, sysfs=str(tmp_path), pci_bdf=bdf)
+        assert info["threads"] == D.host_thread_plan(2, os.cpu_count() or 1)
+        assert info["numa_cpus"] == len({mine[0], mine[-1]}) and os.sched_getaffinity(0) == {mine[0], mine[-1]}
+        assert os.environ["OMP_NUM_THREADS"] == str(info["threads"])
+    finally:
+        os.sched_setaffinity(0, before_aff)
+        torch.set_num_threads(before_threads)
+        os.environ.pop("OMP_NUM_THREADS", None)
