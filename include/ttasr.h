@@ -88,6 +88,14 @@ typedef struct ttasr_gen_opts {
 /* Geometry limits (TTASR_E_INVALID otherwise): d_model <= 1280, vocab <= 53248 (every Whisper checkpoint: <= 1280, <= 51866),
  * n_mels % 8 == 0, ffn_dim % 64 == 0. */
 TTASR_API int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx);
+/* A further context on the SAME GPU that shares `owner`'s device weights instead of loading its own copy (round 6): own stream,
+ * own KV pools / workspaces / search state / captured graphs / kernel options, sized for max_batch rows (<= 0: the owner's) -
+ * and zero bytes of weights (3.1 GB + the 1.9 GB packed decoder copies of large-v3 stay resident once).  What a host needs to keep
+ * two batches in flight on one GPU (pass i + 1's log-mel / encoder under pass i's latency-bound decode chain: +27 % audio-s/s,
+ * DESIGN.md 4.11) - the reference's folder loop is strictly serial (asr_core.py:151).  The owner's weights must be finalized; from
+ * then on they are read-only for every context that shares them (ttasr_load_tensor* return TTASR_E_INVALID).  Contexts may be
+ * destroyed in any order: an owner that is destroyed first stays alive, unusable, until its last sharer is gone. */
+TTASR_API int ttasr_create_shared(ttasr_ctx* owner, int32_t max_batch, ttasr_ctx** out_ctx);
 TTASR_API void ttasr_destroy(ttasr_ctx* ctx);
 /* Message of the last failing call on this context (ctx == NULL: last ttasr_create failure). */
 TTASR_API const char* ttasr_last_error(const ttasr_ctx* ctx);

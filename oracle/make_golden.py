@@ -31,7 +31,7 @@ torch.manual_seed(0)
 torch.set_grad_enabled(False)
 
 
-def hf_model(dims, seed=0, dtype=torch.float32):
+def hf_model(dims, seed=0, dtype=torch.float32, profile="gauss"):
     st = SpecialTokens.for_vocab(dims.vocab)
     cfg = WhisperConfig(
         vocab_size=dims.vocab, num_mel_bins=dims.n_mels, d_model=dims.d_model,
@@ -41,7 +41,7 @@ def hf_model(dims, seed=0, dtype=torch.float32):
         pad_token_id=st.eot, bos_token_id=st.eot, eos_token_id=st.eot, decoder_start_token_id=st.sot,
         activation_function="gelu", attn_implementation="eager")
     model = WhisperForConditionalGeneration(cfg).eval()
-    sd = {k: torch.from_numpy(v) for k, v in synth.iter_weights(dims, seed)}
+    sd = {k: torch.from_numpy(v) for k, v in synth.iter_weights(dims, seed, profile)}
     sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
@@ -107,9 +107,9 @@ def golden_mel():
     print("mel.npz", {k: v.shape for k, v in list(out.items())[:4]})
 
 
-def golden_micro():
+def golden_micro(profile="gauss", fname="micro.npz"):
     dims = PRESETS["micro"]
-    model, st = hf_model(dims)
+    model, st = hf_model(dims, profile=profile)
     fe = WhisperFeatureExtractor(feature_size=dims.n_mels, chunk_length=1)
     n = dims.n_frames * 160
     pcm = np.stack([synth.noise_clip(i, n) for i in range(3)])
@@ -132,13 +132,18 @@ def golden_micro():
     out["cross_k1"] = cc.layers[1].keys.numpy()
     raw, toks, _, _ = hf_greedy(model, st, enc, prompt + [st.no_timestamps], 24, False, suppress, begin_suppress)
     out["nots_logits"], out["nots_tokens"] = raw, toks
-    np.savez_compressed(os.path.join(OUT, "micro.npz"), **out)
-    print("micro.npz tokens(ts)", toks.T.tolist()[0][:12], "enc", enc.shape)
+    if profile != "gauss":   # the waveforms / features are micro.npz's; what this profile adds is how peaked the attention is
+        out.pop("pcm")
+        o = model.model.decoder(input_ids=torch.tensor([prompt + [7, 9, 11, 13]] * 3), encoder_hidden_states=enc, output_attentions=True)
+        out["self_attn_pos0_share"] = np.array([float(a[:, :, 1:, 0].mean()) for a in o.attentions])    # mean weight on position 0
+        out["cross_attn_max_share"] = np.array([float(a.max(-1).values.mean()) for a in o.cross_attentions])
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "tokens(ts)", toks.T.tolist()[0][:12], "enc", enc.shape, {k: v for k, v in out.items() if "share" in k})
 
 
-def golden_tiny():
+def golden_tiny(profile="gauss", fname="tiny.npz"):
     dims = PRESETS["tiny"]
-    model, st = hf_model(dims)
+    model, st = hf_model(dims, profile=profile)
     fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
     pcm = [synth.noise_clip(0), synth.tonal_clip(1)]
     mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
@@ -159,7 +164,7 @@ def golden_tiny():
         out[f"{tag}_logits_stride"] = raw[:, :, ::97]
         out[f"{tag}_no_speech"] = torch.softmax(torch.from_numpy(plog[:, 0]), -1)[:, st.no_speech].numpy()
         print("tiny", tag, toks.T.tolist())
-    np.savez_compressed(os.path.join(OUT, "tiny.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
 def golden_rules():
@@ -245,14 +250,14 @@ def golden_f16():
     _golden_lowp(torch.float16, "tiny_f16.npz", "tiny f16")
 
 
-def _golden_lowp(dtype, fname, label):
+def _golden_lowp(dtype, fname, label, profile="gauss"):
     """Golden set G5: the SAME tiny-geometry model with every parameter cast to bfloat16 and HF's
     own bf16 arithmetic (residual stream, LayerNorm and logits all in bf16) - the precision regime of the reference's
     GPU path (asr_core.py:141 float16; this build measures in bf16).  Stored per greedy step and clip: the token HF picks,
     and the top-2 margin of the PROCESSED scores, so a bf16 engine can be held to token equality wherever the reference
     itself is not within rounding distance of a tie."""
     dims = PRESETS["tiny"]
-    model, st = hf_model(dims, dtype=dtype)
+    model, st = hf_model(dims, dtype=dtype, profile=profile)
     fe = WhisperFeatureExtractor(feature_size=dims.n_mels)
     pcm = [synth.noise_clip(0), synth.tonal_clip(1), synth.noise_clip(2), synth.burst_clip(3)]
     mel = np.stack([fe(p, sampling_rate=16000, return_tensors="np")["input_features"][0] for p in pcm])
@@ -319,8 +324,22 @@ def golden_beam():
     np.savez_compressed(os.path.join(OUT, "beam_hf.npz"), **out)
 
 
+def golden_trained():
+    """Round 6: the micro / tiny fixtures once more on the "trained" weight profile of synth.py
+    (heavy-tailed matrices, LayerNorm outlier channels, two massive residual channels, an attention sink on decoder position 0):
+    HF in f32 (micro: every intermediate; tiny: encoder slice, step logits, greedy tokens) and HF's own bf16 / fp16 arithmetic on
+    the cast tiny model (tokens + top-2 margins per step, like G5 / G7)."""
+    golden_micro("trained", "micro_trained.npz")
+    golden_tiny("trained", "tiny_trained.npz")
+    _golden_lowp(torch.bfloat16, "tiny_trained_bf16.npz", "tiny trained bf16", "trained")
+    _golden_lowp(torch.float16, "tiny_trained_f16.npz", "tiny trained f16", "trained")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--trained-only" in sys.argv:   # round 6: adds the *_trained*.npz fixtures without touching the older ones
+        golden_trained()
+        sys.exit(0)
     if "--f16-only" in sys.argv:      # round 3: adds tests/golden/tiny_f16.npz without touching the older fixtures
         golden_f16()
         sys.exit(0)

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libttasr.so")
 
 # every symbol include/ttasr.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
-    "ttasr_create", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
+    "ttasr_create", "ttasr_create_shared", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
     "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_log_mel_windows", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
     "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_capped", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
     "ttasr_set_option", "ttasr_phase_ms", "ttasr_encoder_kernel_ms", "ttasr_bench_kernel", "ttasr_bench_kernel_signature", "ttasr_sync",
@@ -57,6 +57,7 @@ def load() -> C.CDLL:
     vp, i32, i64, f32p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_float)
     i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
     lib.ttasr_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(vp)]
+    lib.ttasr_create_shared.argtypes = [vp, i32, C.POINTER(vp)]
     lib.ttasr_destroy.argtypes = [vp]
     lib.ttasr_destroy.restype = None
     lib.ttasr_last_error.argtypes = [vp]

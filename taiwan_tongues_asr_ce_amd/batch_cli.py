@@ -117,7 +117,7 @@ def summarise(results: List[Dict]) -> Dict:
 def process_audio_folder(folder_path: str, model=None, model_path: str = "models", device: str = "cuda",
                          device_index: int = 0, compute_type: str = "float16", max_batch: int = 30, output_json: Optional[str] = None, rank: int = 0,
                          world: int = 1, load_audio: Callable = _load_audio, log: Callable = print,
-                         group_files: int = 0) -> Optional[Dict]:
+                         group_files: int = 0, pipeline_depth: int = 0) -> Optional[Dict]:
     files = list_audio_files(folder_path)
     if not files:
         log(f"no audio files in {folder_path}")
@@ -125,7 +125,7 @@ def process_audio_folder(folder_path: str, model=None, model_path: str = "models
     if model is None:
         from .model import WhisperModel
         model = WhisperModel(model_path, device=device, device_index=device_index, compute_type=compute_type,
-                             max_batch=max_batch)
+                             max_batch=max_batch, pipeline_depth=max(1, pipeline_depth))
     mine = files[rank::world]                                   # shard by file
     results = []
     many = getattr(model, "transcribe_many", None)
@@ -136,22 +136,43 @@ def process_audio_folder(folder_path: str, model=None, model_path: str = "models
         # MI355X-first: `group` files advance in lock step through one engine pass per window round; every file keeps the
         # sequential algorithm (own seek / prompt / fallback), so the outputs equal the one-by-one run
         kw = {k: v for k, v in TRANSCRIBE_KWARGS.items() if k != "vad_filter"}   # no VAD source configured: all-speech
-        for g in range(0, len(mine), group):
-            part = mine[g:g + group]
-            audios, loaded = [], []
-            for f in part:
+        parts = [mine[g:g + group] for g in range(0, len(mine), group)]
+        # round 6: with pipeline_depth > 1 the groups are transcribed by that many engine contexts of the model at once (one shared
+        # copy of the weights; one group's log-mel / encoder under another's decode) - same groups, same results, in file order.
+        # Audio is loaded a few groups ahead only (a folder may hold many hours).
+        depth = max(1, int(pipeline_depth or getattr(model, "pipeline_depth", 1)))
+        groups_fn = getattr(model, "transcribe_groups", None) if depth > 1 else None
+        span = 2 * depth if groups_fn is not None else 1
+        for g0 in range(0, len(parts), span):
+            chunk = parts[g0:g0 + span]
+            loaded_of, audios_of = [], []
+            for part in chunk:
+                audios, loaded = [], []
+                for f in part:
+                    try:
+                        audios.append(load_audio(f))
+                        loaded.append(None)
+                    except Exception as e:
+                        loaded.append(e)
+                audios_of.append(audios)
+                loaded_of.append(loaded)
+            done_of = None
+            if groups_fn is not None and len(chunk) > 1:
                 try:
-                    audios.append(load_audio(f))
-                    loaded.append(None)
+                    done_of = groups_fn(audios_of, pipeline_depth=depth, **kw)
                 except Exception as e:
-                    loaded.append(e)
-            try:
-                done = iter(many(audios, **kw)) if audios else iter(())
-                segs = [err if err is not None else next(done)[0] for err in loaded]
-            except Exception as e:  # engine-level failure of the group: fall back to one by one
-                log(f"group transcription failed ({e}); retrying file by file")
-                segs = [None] * len(part)
-            results.extend(transcribe_file(model, f, load_audio, log, segments=sg) for f, sg in zip(part, segs))
+                    log(f"pipelined transcription failed ({e}); retrying group by group")
+            for gi, part in enumerate(chunk):
+                try:
+                    if done_of is not None:
+                        done = iter(done_of[gi])
+                    else:
+                        done = iter(many(audios_of[gi], **kw)) if audios_of[gi] else iter(())
+                    segs = [err if err is not None else next(done)[0] for err in loaded_of[gi]]
+                except Exception as e:  # engine-level failure of the group: fall back to one by one
+                    log(f"group transcription failed ({e}); retrying file by file")
+                    segs = [None] * len(part)
+                results.extend(transcribe_file(model, f, load_audio, log, segments=sg) for f, sg in zip(part, segs))
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world
@@ -177,6 +198,9 @@ def main(argv=None) -> int:
     ap.add_argument("--group-files", type=int, default=0,
                     help="files transcribed in lock step per engine pass (0 = as many as fit: max_batch // beam; 1 = one by one)")
     ap.add_argument("--max-batch", type=int, default=30, help="decode rows of the engine (files in a group x beam 5)")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="groups of files in flight per GPU (engine contexts sharing one copy of the weights; 1 = the reference's "
+                         "serial loop, asr_core.py:151); results do not depend on it")
     args = ap.parse_args(argv)
     if not os.path.exists(args.folder):
         print(f"folder does not exist: {args.folder}")
@@ -187,7 +211,7 @@ def main(argv=None) -> int:
         rank, world, local = init_process_group()
     process_audio_folder(args.folder, model_path=args.model, device="cuda", device_index=local,
                          compute_type=args.compute_type, rank=rank, world=world, group_files=args.group_files,
-                         max_batch=args.max_batch)
+                         max_batch=args.max_batch, pipeline_depth=args.pipeline_depth)
     return 0
 
 

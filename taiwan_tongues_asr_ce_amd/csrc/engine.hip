@@ -38,8 +38,39 @@ const char* ttasr_version(void) { return "ttasr 0.4 (gfx950, HIP; f32 | bf16 | f
 
 const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static int create_impl(const ttasr_config* cfg, int device_id, ttasr_ctx* owner, ttasr_ctx** out_ctx);
+
 int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
+  return guarded(nullptr, [&]() -> int { return create_impl(cfg, device_id, nullptr, out_ctx); });
+}
+
+int ttasr_create_shared(ttasr_ctx* owner, int32_t max_batch, ttasr_ctx** out_ctx) {
   return guarded(nullptr, [&]() -> int {
+  if (!owner || !out_ctx) return fail(nullptr, TTASR_E_INVALID, "owner/out_ctx is NULL");
+  *out_ctx = nullptr;
+  if (owner->weight_owner) owner = owner->weight_owner;   // sharing with a sharer = sharing with its owner
+  if (!owner->finalized) return fail(nullptr, TTASR_E_INVALID, "the owner's weights are not finalized (ttasr_finalize_weights first)");
+  if (owner->destroy_pending) return fail(nullptr, TTASR_E_INVALID, "the owner context was destroyed");
+  ttasr_config cfg = owner->cfg;
+  if (max_batch > 0) cfg.max_batch = max_batch;
+  return create_impl(&cfg, owner->device, owner, out_ctx);
+  });
+}
+
+// the weight pointers of `o` (and what the kernels need to know about their layout) into `c`: nothing is copied on the device
+static void adopt_weights(ttasr_ctx* c, ttasr_ctx* o) {
+  c->conv1_w = o->conv1_w; c->conv2_w = o->conv2_w; c->emb = o->emb; c->dpos = o->dpos; c->emb_sh = o->emb_sh;
+  c->conv1_b = o->conv1_b; c->conv2_b = o->conv2_b; c->epos = o->epos; c->elnf_g = o->elnf_g; c->elnf_b = o->elnf_b;
+  c->dlnf_g = o->dlnf_g; c->dlnf_b = o->dlnf_b;
+  c->enc = o->enc; c->dec = o->dec;
+  c->dec_narrow = o->dec_narrow; c->weights_packed = o->weights_packed;
+  c->finalized = true;
+  c->weight_owner = o;
+  o->sharers.fetch_add(1);
+}
+
+static int create_impl(const ttasr_config* cfg, int device_id, ttasr_ctx* owner, ttasr_ctx** out_ctx) {
+  {
   if (!cfg || !out_ctx) return fail(nullptr, TTASR_E_INVALID, "cfg/out_ctx is NULL");
   *out_ctx = nullptr;
   if (cfg->d_model <= 0 || cfg->n_heads <= 0 || cfg->d_model != cfg->n_heads * 64)
@@ -76,11 +107,13 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   gemm_tiles_init(device_id);
   {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
     const size_t d = p->d, ffn = p->ffn, T = p->T, B = p->maxB;
-    const size_t w = ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);
+    const size_t w = owner ? 0 : ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);
     const size_t act = B * T * (4 * d + 3 * d + ffn + 2 * d) + (size_t)cfg->dec_layers * 2 * B * T * d + (size_t)cfg->dec_layers * 2 * B * cfg->n_text_ctx * d;
     p->arena_hint = (w + act) * p->esz;
   }
-  int rc = build_weights(p);
+  int rc = 0;
+  if (owner) adopt_weights(p, owner);   // before anything can fail below: ttasr_destroy (die) releases the share again
+  else rc = build_weights(p);
   if (rc) return die(rc);
   rc = build_workspaces(p);
   if (rc) return die(rc);
@@ -105,7 +138,7 @@ int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
 #endif
   *out_ctx = c.release();
   return TTASR_OK;
-  });
+  }
 }
 
 int ttasr_set_option(ttasr_ctx* c, const char* key, int32_t value) {
@@ -125,6 +158,11 @@ void ttasr_destroy(ttasr_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->sharers.load() > 0 && !c->destroy_pending) {   // other contexts still read these weights: the last of them frees this one
+    c->destroy_pending = true;
+    return;
+  }
+  ttasr_ctx* owner = c->weight_owner;
   drop_graphs(c);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   for (auto& e : c->enc_ev) hipEventDestroy(e);
@@ -132,13 +170,21 @@ void ttasr_destroy(ttasr_ctx* c) {
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
+  if (owner && owner->sharers.fetch_sub(1) == 1 && owner->destroy_pending) ttasr_destroy(owner);   // we were the last sharer
 }
 
 
 
+static int weights_writable(ttasr_ctx* c) {
+  if (c->weight_owner) return fail(c, TTASR_E_INVALID, "this context shares another context's weights (ttasr_create_shared): they are read-only");
+  if (c->sharers.load() > 0) return fail(c, TTASR_E_INVALID, "%d context(s) share these weights: they are read-only", c->sharers.load());
+  return 0;
+}
+
 int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const int64_t* dims, int32_t ndim) {
   return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
+  TRY(weights_writable(c));
   if (!name || !data || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
   int64_t n = 1;
   for (int i = 0; i < ndim; ++i) n *= dims[i];
@@ -152,6 +198,7 @@ int ttasr_load_tensor(ttasr_ctx* c, const char* name, const float* data, const i
 int ttasr_load_tensor_device(ttasr_ctx* c, const char* name, const void* data_dev, int32_t dtype, const int64_t* dims, int32_t ndim) {
   return guarded(c, [&]() -> int {
   if (!c) return TTASR_E_INVALID;
+  TRY(weights_writable(c));
   if (!name || !data_dev || !dims) return fail(c, TTASR_E_INVALID, "NULL argument");
   if (dtype != TTASR_DTYPE_F32 && dtype != TTASR_DTYPE_BF16 && dtype != TTASR_DTYPE_F16)
     return fail(c, TTASR_E_INVALID, "dtype must be 0 (float32), 1 (bfloat16 bits) or 2 (float16 bits)");

@@ -110,6 +110,13 @@ struct ttasr_ctx {
                               // (K-split GEMMs), so 3 prompt positions x 32 clips cost 6.4 ms against 8.8 ms as three steps
   bool enc_res_epilogue = false;  // option enc_residual_epilogue: keep the f32 residual add in the encoder GEMM epilogues (A/B testing)
   DecState st{}; int32_t* prompt_dev = nullptr; int32_t* plen_dev = nullptr; uint8_t* mask_dev = nullptr;
+  // round 6: several contexts on one GPU may share ONE copy of the device weights (ttasr_create_shared: the pipelined folder
+  // path runs pass i + 1's log-mel / encoder under pass i's decode from two contexts; a second private copy would double the
+  // 5 GB of large-v3).  A sharer holds `weight_owner` and counts in the owner's `sharers`; an owner that is destroyed while
+  // sharers live is only marked (`destroy_pending`) and freed by the last of them.  Weights are read-only once shared.
+  ttasr_ctx* weight_owner = nullptr;
+  std::atomic<int> sharers{0};
+  bool destroy_pending = false;
   int32_t* row_cap_dev = nullptr;   // [maxB] per-row token budgets (st.row_cap; ttasr_generate_capped), "no budget" = 0x7f7f7f7f
   bool ragged_exit = true;          // option ragged_exit [1]: finished rows (st.done) leave the attention kernels of the decode step
                                     // (0: the static batch of rounds 1-5 - every row streams its cross-KV until the last one ends; A/B)

@@ -48,19 +48,31 @@ def default_suppress(st: SpecialTokens, vocab: int) -> List[int]:
 
 
 class Engine:
-    def __init__(self, dims: WhisperDims, compute_type: int = COMPUTE_BF16, max_batch: int = 1, device: int = 0):
+    def __init__(self, dims: WhisperDims, compute_type: int = COMPUTE_BF16, max_batch: int = 1, device: int = 0,
+                 share_weights_with: Optional["Engine"] = None):
+        """share_weights_with: another Engine on the same GPU whose (finalized) device weights this one reads instead of loading
+        its own copy (ttasr_create_shared): a second context for keeping two batches in flight costs workspaces only."""
         self.lib = _lib.load()
         self.dims = dims
         self.compute_type = compute_type
         self.max_batch = max_batch
         self.device = device
-        cfg = _lib.Config(dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, dims.enc_layers,
-                          dims.dec_layers, dims.vocab, dims.n_text_ctx, compute_type, max_batch, 0)
         h = C.c_void_p()
-        rc = self.lib.ttasr_create(C.byref(cfg), device, C.byref(h))
+        if share_weights_with is not None:
+            o = share_weights_with
+            if o.dims != dims or o.compute_type != compute_type or o.device != device:
+                raise ValueError("a weight-sharing engine must have its owner's geometry, compute type and device")
+            rc = self.lib.ttasr_create_shared(o.h, max_batch, C.byref(h))
+            what = "ttasr_create_shared"
+        else:
+            cfg = _lib.Config(dims.n_mels, dims.n_audio_ctx, dims.d_model, dims.n_heads, dims.ffn_dim, dims.enc_layers,
+                              dims.dec_layers, dims.vocab, dims.n_text_ctx, compute_type, max_batch, 0)
+            rc = self.lib.ttasr_create(C.byref(cfg), device, C.byref(h))
+            what = "ttasr_create"
         if rc != 0:
-            raise TtasrError(f"ttasr_create failed ({rc}): {self.lib.ttasr_last_error(None).decode()}")
+            raise TtasrError(f"{what} failed ({rc}): {self.lib.ttasr_last_error(None).decode()}")
         self.h = h
+        self.shares_weights = share_weights_with is not None
         self.special = SpecialTokens.for_vocab(dims.vocab)
         self.audio_ctx = dims.n_audio_ctx
 

@@ -77,9 +77,117 @@ def tensor_specs(dims: WhisperDims) -> List[Tuple[str, Tuple[int, ...], str]]:
     return out
 
 
-def make_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0) -> np.ndarray:
+# ---------------------------------------------------------------------------------------------------------------------------
+# Second weight distribution (round 6): "trained".  The product deploys FINE-TUNED checkpoints
+# (train_asr.py:518-545 -> asr_core.py:141), never N(0, 1/n).  No checkpoint exists offline, so this profile reproduces the
+# STATISTICS that separate a trained transformer from a freshly initialised one and that 16-bit kernels are sensitive to:
+#   * heavy-tailed matrices: Student-t with 4 degrees of freedom, scaled to the same variance 1 / fan_in (kurtosis is unbounded at
+#     nu = 4: a handful of entries per matrix are 10-20 sigma);
+#   * LayerNorm gamma log-normal (sigma 0.4) with three channels per vector multiplied by 10 ... 30, beta 0.1 N with three
+#     channels of +-(1 ... 3);
+#   * MASSIVE ACTIVATIONS: two residual channels (massive_channels(d)) carry values of 4 ... 7 x sqrt(d) (140 ... 250 at large-v3
+#     width) - in the encoder through the stem's second convolution bias (+5 sqrt(d) after GELU on every frame) and the fc2 bias
+#     of the first layer (-4 sqrt(d)), in the decoder through the first layer's fc2 bias (+5 sqrt(d), every position) and the
+#     learned position embedding of position 0 (+7 sqrt(d): the first token is special, as in trained language models); after
+#     LayerNorm those channels sit at 15-25 sigma and every other channel shrinks ~6 x;
+#   * an ATTENTION SINK: Whisper's k_proj has no bias (modeling_whisper.py:279), so the sink is built the way trained models
+#     build it - position 0's massive channel makes its key an outlier that the queries' bias is aligned with (q_proj.bias of the
+#     decoder self-attention gets a component along W_k's column of the massive channel), so a large share of every decoder
+#     self-attention row lands on the first token.
+# Same Philox streams per tensor name: any tensor can be regenerated alone.  The default profile ("gauss") is untouched.
+PROFILES = ("gauss", "trained")
+
+
+def massive_channels(d: int) -> Tuple[int, int]:
+    """The two residual channels that carry massive activations in the "trained" profile."""
+    return d // 3, d - 7
+
+
+def _student_t(g: np.random.Generator, shape, nu: float = 4.0) -> np.ndarray:
+    """Unit-variance Student-t(nu) as float32 (var of t_nu = nu / (nu - 2))."""
+    x = g.standard_normal(shape, dtype=np.float32)
+    chi = g.chisquare(nu, size=shape).astype(np.float32)
+    x *= np.sqrt(np.float32(nu) / chi, dtype=np.float32)
+    x *= np.float32(math.sqrt((nu - 2.0) / nu))
+    return x
+
+
+def _make_trained(name: str, shape: Tuple[int, ...], kind: str, seed: int) -> np.ndarray:
+    g = _rng(seed ^ 0x7261696E, name)     # its own stream family ("rain"): never the gauss profile's numbers
+    d = shape[-1] if kind in ("embed",) else shape[0]
+    if kind == "linear":
+        x = _student_t(g, shape) * np.float32(1.0 / math.sqrt(shape[1]))
+        if name.endswith(".encoder_attn.out_proj.weight"):
+            x *= np.float32(4.0)     # a trained decoder LEANS on the audio: without this the massive channels (which shrink every
+        return x                     # other channel ~6 x in each LayerNorm) leave the tokens almost independent of the clip
+    if kind == "conv":
+        return _student_t(g, shape) * np.float32(1.0 / math.sqrt(shape[1] * shape[2]))
+    if kind == "gamma":
+        x = np.exp(np.float32(0.4) * g.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        idx = g.choice(shape[0], size=3, replace=False)
+        mult = g.uniform(10.0, 30.0, size=3).astype(np.float32)
+        if name == "model.decoder.layer_norm.weight":
+            # the FINAL decoder LayerNorm multiplies the tied, heavy-tailed embedding: with an amplified or a massive channel one
+            # token - the largest embedding entry in that channel - wins every position.  A trained model suppresses them there.
+            x[list(massive_channels(shape[0]))] = np.float32(0.02)
+        else:
+            x[idx] *= mult
+        return x
+    if kind == "beta":
+        x = np.float32(0.1) * g.standard_normal(shape, dtype=np.float32)
+        idx = g.choice(shape[0], size=3, replace=False)
+        x[idx] = (g.uniform(1.0, 3.0, size=3) * g.choice([-1.0, 1.0], size=3)).astype(np.float32)
+        return x
+    if kind == "bias":
+        x = np.float32(0.02) * g.standard_normal(shape, dtype=np.float32)
+        if name.endswith("fc2.bias") or name == "model.encoder.conv2.bias":
+            c1, c2 = massive_channels(shape[0])
+            r = np.float32(math.sqrt(shape[0]))      # magnitudes scale with sqrt(d): the same share of a row's norm at every width
+            if name == "model.encoder.conv2.bias":
+                x[c1] = np.float32(5.0) * r          # 179 at d = 1280
+            elif name == "model.encoder.layers.0.fc2.bias":
+                x[c2] = np.float32(-4.0) * r         # -143
+            elif name == "model.decoder.layers.0.fc2.bias":
+                x[c2] = np.float32(5.0) * r          # +179
+        return x
+    if kind == "embed":
+        x = _student_t(g, shape) * np.float32(0.05)
+        c1, _ = massive_channels(shape[1])
+        if name == "model.decoder.embed_positions.weight":
+            x[0, c1] = np.float32(7.0 * math.sqrt(shape[1]))     # +250 at d = 1280: the first position is special
+        # (token embeddings stay outlier-free: they are tied to the output projection, where a massive channel would add the same
+        #  huge constant to a handful of logits)
+        return x
+    raise ValueError(kind)
+
+
+def _sink_query_bias(sd_get, prefix: str, d: int, seed: int) -> np.ndarray:
+    """q_proj.bias of a decoder self-attention block in the "trained" profile: the plain 0.02 N bias plus, per head, a component
+    along that head's key direction of the massive channel c1 (W_k[:, c1] restricted to the head), sized so that the score of
+    position 0's key (its LayerNorm output is ~sqrt(d) in that channel: the position embedding dominates the row) exceeds the
+    others by ~12 nats - about three standard deviations of the scores this profile produces: the attention sink."""
+    c1, _ = massive_channels(d)
+    wk = sd_get(prefix + ".k_proj.weight")            # [d, d]
+    col = wk[:, c1].astype(np.float64)                # every head's key response to the massive channel
+    b = _make_trained(prefix + ".q_proj.bias", (d,), "bias", seed).astype(np.float64)
+    for h in range(d // 64):
+        seg = slice(64 * h, 64 * h + 64)
+        n2 = float(col[seg] @ col[seg])
+        if n2 > 0:
+            b[seg] += 8.0 * (12.0 / math.sqrt(d)) * col[seg] / n2   # 8 = 1 / head_dim ** -0.5 (HF scales W_q h + b_q by it)
+    return b.astype(np.float32)
+
+
+def make_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0, profile: str = "gauss") -> np.ndarray:
     if kind == "sinusoid":
         return sinusoids(shape[0], shape[1])
+    if profile == "trained":
+        if kind == "bias" and ".decoder." in name and name.endswith(".self_attn.q_proj.bias"):
+            prefix = name[: -len(".q_proj.bias")]
+            return _sink_query_bias(lambda n: _make_trained(n, (shape[0], shape[0]), "linear", seed), prefix, shape[0], seed)
+        return _make_trained(name, shape, kind, seed)
+    if profile != "gauss":
+        raise ValueError(f"profile {profile!r} (known: {PROFILES})")
     g = _rng(seed, name)
     x = g.standard_normal(shape, dtype=np.float32)
     if kind == "linear":
@@ -99,13 +207,16 @@ def make_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0) -> 
     return x
 
 
-def iter_weights(dims: WhisperDims, seed: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
+def iter_weights(dims: WhisperDims, seed: int = 0, profile: str = "gauss") -> Iterator[Tuple[str, np.ndarray]]:
     for name, shape, kind in tensor_specs(dims):
-        yield name, make_tensor(name, shape, kind, seed)
+        if profile == "gauss":
+            yield name, make_tensor(name, shape, kind, seed)      # (positional form: the session-wide test cache wraps it)
+        else:
+            yield name, make_tensor(name, shape, kind, seed, profile)
 
 
-def state_dict(dims: WhisperDims, seed: int = 0) -> Dict[str, np.ndarray]:
-    return dict(iter_weights(dims, seed))
+def state_dict(dims: WhisperDims, seed: int = 0, profile: str = "gauss") -> Dict[str, np.ndarray]:
+    return dict(iter_weights(dims, seed, profile))
 
 
 def noise_clip(i: int, n_samples: int = N_SAMPLES) -> np.ndarray:

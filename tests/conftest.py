@@ -46,11 +46,11 @@ def _synthetic_weight_cache():
     from taiwan_tongues_asr_ce_amd import synth
     orig, cache = synth.make_tensor, {}
 
-    def cached(name, shape, kind, seed=0):
-        key = (name, tuple(shape), kind, seed)
+    def cached(name, shape, kind, seed=0, profile="gauss"):
+        key = (name, tuple(shape), kind, seed, profile)
         a = cache.get(key)
         if a is None:
-            a = orig(name, shape, kind, seed)
+            a = orig(name, shape, kind, seed, profile)
             a.flags.writeable = False
             cache[key] = a
         return a

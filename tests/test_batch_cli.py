@@ -114,3 +114,46 @@ def test_group_mode_batches_files_and_degrades_per_file(tmp_path, monkeypatch):
     model2 = _GroupModel([["x"]] * 5)
     batch_cli.process_audio_folder(str(folder), model=model2, log=lambda *_: None, group_files=1)
     assert model2.groups == [] and len(model2.calls) == 4               # the unreadable file never reaches the model
+
+
+class _PipelinedModel(_GroupModel):
+    """Double with the round-6 entry point: groups in flight on several engine contexts."""
+    pipeline_depth = 2
+
+    def __init__(self, texts, fail_pipeline=False):
+        super().__init__(texts)
+        self.pipelined, self.fail_pipeline = [], fail_pipeline
+
+    def transcribe_groups(self, groups, pipeline_depth=None, **kw):
+        self.pipelined.append((pipeline_depth, [[len(a) for a in g] for g in groups]))
+        if self.fail_pipeline:
+            raise RuntimeError("second context could not be created")
+        return [self.transcribe_many(g, **kw) for g in groups]
+
+
+def test_pipelined_folder_keeps_the_groups_and_the_results(tmp_path, monkeypatch):
+    """pipeline_depth = 2: the SAME groups of files as the serial run - handed to the model a few
+    groups at a time (2 x depth) so that a folder of many hours is not decoded into memory at once - the same results in file
+    order; a failure of the pipelined call degrades to group by group."""
+    monkeypatch.chdir(tmp_path)
+    folder = tmp_path / "audio"; folder.mkdir()
+    sizes = [100 * (i + 1) for i in range(11)]
+    for i, n in enumerate(sizes):
+        _wav(folder / f"f{i:02d}.wav", n)
+    serial = _GroupModel([])
+    want = batch_cli.process_audio_folder(str(folder), model=serial, log=lambda *_: None)
+    assert serial.groups == [[100, 200], [300, 400], [500, 600], [700, 800], [900, 1000], [1100]]
+    piped = _PipelinedModel([])
+    got = batch_cli.process_audio_folder(str(folder), model=piped, log=lambda *_: None)
+    assert piped.groups == serial.groups                                        # identical grouping = identical engine inputs
+    assert [d for d, _ in piped.pipelined] == [2, 2]                            # two calls of 2 x depth = 4 groups, then the rest
+    assert piped.pipelined[0][1] == serial.groups[:4] and piped.pipelined[1][1] == serial.groups[4:]
+    assert got["detailed_results"] == want["detailed_results"]
+    # explicit depth 1 never touches the pipelined entry point; a failing pipeline falls back without losing a file
+    one = _PipelinedModel([])
+    batch_cli.process_audio_folder(str(folder), model=one, log=lambda *_: None, pipeline_depth=1)
+    assert one.pipelined == [] and one.groups == serial.groups
+    broken = _PipelinedModel([], fail_pipeline=True)
+    logs = []
+    res = batch_cli.process_audio_folder(str(folder), model=broken, log=logs.append)
+    assert res["detailed_results"] == want["detailed_results"] and any("pipelined transcription failed" in str(m) for m in logs)

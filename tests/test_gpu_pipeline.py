@@ -1,0 +1,137 @@
+"""GPU: two engine contexts on one GPU sharing ONE copy of the weights, and the pipelined folder path on top of them
+(round 6).
+
+The reference's folder loop is strictly serial - one file, one transcribe() at a time (asr_core.py:151).  One decode batch
+leaves most of an MI355X idle between its dependent launches; two batches in flight measured +27 % audio-s/s,
+but until this round a second context meant a second copy of the weights (5 GB for large-v3) and no caller could reach it.
+`ttasr_create_shared` gives a context its own stream / KV pools / workspaces and the OWNER's weights; `WhisperModel(...,
+pipeline_depth=2).transcribe_groups` / `batch_cli --pipeline-depth 2` run two groups of files at once on two such contexts.
+
+Held here: identical results file by file (same groups -> same engine inputs -> same bits), the weights resident once
+(device-memory deltas), read-only weights once shared, destruction in any order."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from taiwan_tongues_asr_ce_amd import synth
+from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, PRESETS
+
+pytestmark = pytest.mark.gpu
+DIMS = PRESETS["large-v3-w2"]
+
+
+def _weight_bytes(dims, esz=2):
+    """Device bytes of one copy of the weights in a 16-bit engine: every matrix in 16 bits + the fragment-packed decoder copies
+    (all decoder matrices except the cross-KV projections, and the tied embedding) + f32 vectors."""
+    mats = vecs = packed = 0
+    for name, shape, kind in synth.tensor_specs(dims):
+        n = int(np.prod(shape))
+        if len(shape) >= 2 and kind != "sinusoid":
+            mats += n
+            if ".decoder." in name and name.endswith(".weight") and "embed_positions" not in name and \
+                    "encoder_attn.k_proj" not in name and "encoder_attn.v_proj" not in name:
+                packed += n
+        else:
+            vecs += n
+    return (mats + packed) * esz + vecs * 4
+
+
+def _free():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_shared_context_costs_no_weights_and_computes_the_same():
+    from taiwan_tongues_asr_ce_amd.engine import Engine, TtasrError
+    B = 8
+    sd = synth.state_dict(DIMS)
+    clips = [synth.noise_clip(40 + i) if i % 2 else synth.tonal_clip(40 + i) for i in range(2 * B)]
+    f0 = _free()
+    owner = Engine(DIMS, COMPUTE_BF16, B)
+    owner.load_weights(sd.items())
+    owner.sync()
+    f1 = _free()
+    twin = Engine(DIMS, COMPUTE_BF16, B, share_weights_with=owner)
+    twin.sync()
+    f2 = _free()
+    fresh_cost, shared_cost, wbytes = f0 - f1, f1 - f2, _weight_bytes(DIMS)
+    assert wbytes > 400e6                                               # 0.5 GB at this geometry: a visible share of the footprint
+    assert fresh_cost - shared_cost >= 0.8 * wbytes, (fresh_cost, shared_cost, wbytes)
+    assert twin.shares_weights and not owner.shares_weights
+    # weights are read-only once shared - for the sharer and for the owner
+    name, arr = next(iter(sd.items()))
+    for e in (twin, owner):
+        with pytest.raises(TtasrError, match="read-only"):
+            e.load_weights([(name, arr)])
+    with pytest.raises(ValueError):
+        Engine(PRESETS["tiny"], COMPUTE_BF16, B, share_weights_with=owner)     # another geometry cannot share
+    st = owner.special
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+
+    def run(e, batch, out, key):
+        e.log_mel(batch, want_output=False)
+        enc = e.encode(len(batch), want_output=True)
+        opts = e.gen_opts(24, False, suppress_eot=True)
+        r = e.generate([prompt] * len(batch), opts)
+        out[key] = (enc.copy(), r.tokens, r.sum_logprob.copy())
+    serial, conc = {}, {}
+    run(owner, clips[:B], serial, "a")
+    run(owner, clips[B:], serial, "b")
+    th = [threading.Thread(target=run, args=(owner, clips[:B], conc, "a")), threading.Thread(target=run, args=(twin, clips[B:], conc, "b"))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in ("a", "b"):                                                # two contexts at once = the serial runs, bit for bit
+        assert np.array_equal(serial[k][0], conc[k][0]) and serial[k][1] == conc[k][1] and np.array_equal(serial[k][2], conc[k][2]), k
+    # kernel options are per context: changing one on the sharer leaves the owner's results alone
+    twin.set_option("xattn_pipeline", 0)
+    run(twin, clips[:B], conc, "c")
+    assert conc["c"][1] == serial["a"][1]                               # (that option is bit-identical by construction)
+    # destruction in any order: the owner first - the sharer keeps working on the weights the owner held
+    owner.close()
+    run(twin, clips[B:], conc, "d")
+    assert conc["d"][1] == serial["b"][1]
+    twin.close()
+    torch.cuda.synchronize()
+    assert _free() >= f0 - (64 << 20), (f0, _free())                    # everything came back (allocator slack aside)
+
+
+def _files(n):
+    """n recordings of 40-70 s (two to three 30-s windows each), different lengths so that files finish in different rounds."""
+    out = []
+    for i in range(n):
+        a = np.concatenate([synth.tonal_clip(3 * i), synth.noise_clip(3 * i + 1), synth.burst_clip(3 * i + 2)])
+        out.append(np.ascontiguousarray(a[: 16000 * (40 + 5 * (i % 7))]))
+    return out
+
+
+def _flat(results):
+    return [[(round(s.start, 3), round(s.end, 3), s.text, tuple(s.tokens)) for s in segs] for group in results for segs, _ in group]
+
+
+def test_pipelined_folder_path_equals_the_serial_one_file_by_file():
+    from taiwan_tongues_asr_ce_amd.model import WhisperModel
+    files = _files(8)
+    groups = [files[0:2], files[2:4], files[4:6], files[6:8]]                 # max_batch 10 // beam 5 = 2 files per engine pass
+    kw = dict(language="zh", beam_size=5, temperature=0.0, log_prob_threshold=None, compression_ratio_threshold=None,
+              no_speech_threshold=None, max_new_tokens=24)
+    m = WhisperModel("synthetic:large-v3-w2", device="cuda", compute_type="bfloat16", max_batch=10, pipeline_depth=2)
+    f_before = _free()
+    serial = m.transcribe_groups(groups, pipeline_depth=1, **kw)
+    assert len(m._lanes) == 1 and _free() >= f_before - (8 << 20)             # depth 1 never builds a second context
+    piped = m.transcribe_groups(groups, **kw)                                  # the model's own depth: 2
+    assert len(m._lanes) == 2 and m._lanes[1].shares_weights
+    lane_cost = f_before - _free()
+    assert lane_cost < 2.0e9 and lane_cost < 4 * _weight_bytes(DIMS)          # workspaces of a 10-row context, no second weight copy
+    assert _flat(piped) == _flat(serial)
+    assert sum(len(segs) for g in serial for segs, _ in g) >= 8
+    again = m.transcribe_groups(groups, **kw)                                  # and once more on the warm lanes (captured graphs)
+    assert _flat(again) == _flat(serial)
+    # a failure inside one lane surfaces on the caller's thread and leaves the model usable
+    with pytest.raises(Exception):
+        m.transcribe_groups([files[0:2], [np.zeros((2, 2), np.float32)]], **kw)
+    assert _flat(m.transcribe_groups(groups[:2], **kw)) == _flat(serial[:2])
+    m.close()
