@@ -118,6 +118,7 @@ struct ttasr_ctx {
   std::atomic<int> sharers{0};
   bool destroy_pending = false;
   int32_t* row_cap_dev = nullptr;   // [maxB] per-row token budgets (st.row_cap; ttasr_generate_capped), "no budget" = 0x7f7f7f7f
+  int xattn_deep_items = 448;       // option xattn_deep_items: see kernels_attn.hip cross_attn_pipe_kernel (0: never stream deep)
   bool ragged_exit = true;          // option ragged_exit [1]: finished rows (st.done) leave the attention kernels of the decode step
                                     // (0: the static batch of rounds 1-5 - every row streams its cross-KV until the last one ends; A/B)
   RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)

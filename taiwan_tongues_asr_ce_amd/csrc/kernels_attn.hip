@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include <cstdarg>
 #include <cstdio>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // encoder attention, simple form.  Block = 4 waves = 16 queries of one (b, h); K/V tiles of 64 keys
@@ -557,138 +558,194 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
 // 2 43.8 (tools/microbench/xattn_bench.hip, profiles/r4_xattn_pipeline.txt).  At a balanced 2.97 workgroups per CU (B = 38) every
 // form runs 6.42-6.48 TB/s: the gain at B = 32 is a shorter tail of the uneven 3-vs-2 workgroup split, not a faster stream.
 // 16-bit storage, 4 waves, decode step only (no PROBS).
+thread_local int g_xattn_deep_items = 448;   // option xattn_deep_items: live (row, head) items at or below which a workgroup streams
+                                             // DEEP (default 1.75 per CU of 256; 0 = never) - per context, like g_xattn_variant
+constexpr int XATTN_DEEP_U = 8;              // rows per lane and batch of the deep form
 template <typename T, bool NT, bool QSLAB, int U>
 __global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const T* K, const T* V, T* out, const int32_t* done, int H,
-                                                              int Tk, int kv_div, SlabIn sq) {
+                                                              int Tk, int kv_div, int deep_items, SlabIn sq) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   constexpr int VEC = 8, LPR = 8, RPI = 8, NWV = 4;
   extern __shared__ float sc[];  // [Tk] scores, then [NWV][64] partial outputs, [2 * NWV] reductions
   q = sgpr_pin_ptr(q); K = sgpr_pin_ptr(K); V = sgpr_pin_ptr(V); out = sgpr_pin_ptr(out); done = sgpr_pin_ptr(done);
-  H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div);
+  H = sgpr_pin(H); Tk = sgpr_pin(Tk); kv_div = sgpr_pin(kv_div); deep_items = sgpr_pin(deep_items);
   sq.slab = sgpr_pin_ptr(sq.slab); sq.bias = sgpr_pin_ptr(sq.bias); sq.n = sgpr_pin(sq.n); sq.stride = sgpr_pin(sq.stride);
   sq.ld = sgpr_pin(sq.ld);
-  const int b = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slot = blockIdx.y, nrows = gridDim.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
   const int sub = lane % LPR, rin = lane / LPR;
   float* part = sc + Tk;
   float* red = part + NWV * 64;
-  const int bk = kv_div == 1 ? b : b / kv_div;
-  // Round 6: done[b] != 0 = row b of the decode batch is FINISHED (select_kernel set it at an earlier step:
-  // EOT sampled, or the row's token budget reached).  One scalar load, requested here and first needed after the query is in
-  // (row_done_exit below): a live row pays nothing for it.
-  const int done_raw = row_done_issue(done, b, K);
-  const T* Kp = K + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
-  const T* Vp = V + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
+  // Round 6: done[r] != 0 = row r of the decode batch is FINISHED (select_kernel set it at an earlier step:
+  // EOT sampled, or the row's token budget reached) and must not stream its cross-KV any more.  Workgroup (h, slot) therefore
+  // serves the slot-th LIVE row, not row `slot`: the live (row, head) items occupy the FIRST workgroups of the grid, which the
+  // dispatcher spreads evenly over the CUs, and the workgroups behind them exit.  (Letting workgroup (h, b) just test done[b]
+  // was measured first: a kernel is as slow as its most loaded CU, and with a random half of the rows gone most CUs still
+  // held three live workgroups - the cross-KV bytes fell by 44 %, the decode time by 8 %.)  While no row has finished,
+  // slot == row: the first K batch and the query are requested for row `slot` BEFORE the flags are looked at, so the all-live
+  // step (the benchmark) waits for nothing new; only a workgroup whose row moved requests them again.
+  // Lane i holds done[i] (batches of up to 64 rows; wider ones test their own row only).  The flags arrive with the query.
+  const bool remap = nrows <= 64;
+  const int32_t* fp = done ? done + (remap ? min(lane, nrows - 1) : slot) : (const int32_t*)K;   // unconditional load (K: any valid address)
+  const int flag = *fp;
+  int b = slot;
+  const T* Kp; const T* Vp;
+  auto place = [&](int row) {
+    const int bk = kv_div == 1 ? row : row / kv_div;
+    Kp = K + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
+    Vp = V + ((int64_t)bk * H + h) * Tk * 64 + sub * VEC;
+  };
+  place(b);
   const int n_it = (Tk + NWV * RPI - 1) / (NWV * RPI);
   // iteration `it` covers rows it * 32 .. + 31, wave w its rows 8 w .. 8 w + 7: the order of the kernel above (bit-identical).
   // (Each wave streaming its own contiguous quarter of the frames instead measured 1.0 us slower: DESIGN.md 4.11.)
   const int trow = wave * RPI + rin;
   constexpr int TSTEP = NWV * RPI;
   const int tend = Tk;
-  auto issue = [&](const T* base, int it0, u32x4_t (&r)[U]) {
+  auto issue = [&](const T* base, int it0, auto& r) {
+    constexpr int NR = (int)std::extent<std::remove_reference_t<decltype(r)>>::value;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < NR; ++u) {
       const int t = min((it0 + u) * TSTEP + trow, Tk - 1);   // clamped, unconditional
       if constexpr (NT) r[u] = __builtin_nontemporal_load((const u32x4_t*)(base + (int64_t)t * 64));
       else r[u] = *(const u32x4_t*)(base + (int64_t)t * 64);
     }
   };
-  u32x4_t ra[U], rb[U];
-  issue(Kp, 0, ra);
+  u32x4_t ra0[U];
+  issue(Kp, 0, ra0);
   float qv[VEC];
-  if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)b * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
-  else RowVec<T>::load(q + (int64_t)b * d + h * 64 + sub * VEC, qv);
-  // row_done_exit: a finished row leaves HERE - workgroup-uniform, before the second K batch is requested - and takes its
-  // 2 * Tk * 128 B of cross-KV (384 KB per (row, head) and layer at large-v3: 78 % of a decode step's bytes are these per-ROW
-  // streams) out of the step; `out` keeps the row's last live values (finite; select_kernel ignores a finished row's logits).
-  // The grid, and with it every captured graph, is unchanged, and no live row's arithmetic depends on a neighbour: the live
-  // rows' outputs are bit-identical to the static batch's.  The exit sits AFTER the first K batch and the query were requested
-  // so that a live row waits for nothing new (a finished row wastes that one batch: 3 of the 3 000 rows per lane pair); the
-  // never-taken store (Tk < 0 is unknown to the compiler) keeps a use of the batch on this side of the branch, without which
-  // the optimiser sinks the loads BELOW it - behind the wait for done[b].
-  if (done && done_raw) { if (Tk < 0) sc[0] = __uint_as_float(ra[0].x ^ ra[U - 1].x) + qv[0]; return; }
-  float mloc = -1e30f;
-  auto score = [&](int it0, const u32x4_t (&r)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = (it0 + u) * TSTEP + trow;
-      float kf[VEC];
-      up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), kf);
-      float s = 0.f;
-      if (t < tend) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kf[j], s);
+  auto fetch_q = [&](int row) {
+    if constexpr (QSLAB) load_row_slabs<T>(sq, (int64_t)row * d + h * 64 + sub * VEC, h * 64 + sub * VEC, qv);
+    else RowVec<T>::load(q + (int64_t)row * d + h * 64 + sub * VEC, qv);
+  };
+  fetch_q(b);
+  int n_live = nrows;
+  if (done) {
+    // The exits below are workgroup-uniform and sit AFTER the first K batch and the query were requested; the never-taken store
+    // (Tk < 0 is unknown to the compiler) keeps a use of that batch on this side of the branch - without it the optimiser sinks
+    // the loads BELOW the branch, behind the wait for the flags.  A finished item's `out` row keeps its last live values
+    // (finite; select_kernel ignores a finished row's logits); no live row's arithmetic depends on a neighbour, so the live
+    // rows' outputs are bit-identical to the static batch's, whichever workgroup computes them.
+#define TTASR_ROW_DONE_EXIT() do { if (Tk < 0) sc[0] = __uint_as_float(ra0[0].x ^ ra0[U - 1].x) + qv[0]; return; } while (0)
+    if (remap) {
+      const unsigned long long live = __ballot(lane < nrows && flag == 0);
+      n_live = __popcll(live);
+      if (slot >= n_live) TTASR_ROW_DONE_EXIT();
+      // the slot-th live row: the lane whose bit is set with exactly `slot` set bits below it
+      const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+      const unsigned long long hit = __ballot(((live >> lane) & 1ull) != 0 && below == slot);
+      const int row = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+      if (row != slot) {   // a row before this one has finished: this workgroup serves another row - request its stream and query
+        b = row;
+        place(b);
+        issue(Kp, 0, ra0);
+        fetch_q(b);
       }
-      s = group_reduce<LPR>(s, OpSum{});
-      if (t < tend) {
-        if (sub == 0) sc[t] = s;
-        mloc = fmaxf(mloc, s);
+    } else if (__builtin_amdgcn_readfirstlane(flag)) {
+      TTASR_ROW_DONE_EXIT();
+    }
+#undef TTASR_ROW_DONE_EXIT
+  }
+  // The stream itself, with UU rows per lane and batch (two batches in flight).  UU = U = 3 is the measured optimum when the grid
+  // over-subscribes the chip (640 workgroups: 2.5 per CU, bandwidth-bound, 39 us).  With few LIVE items a workgroup is alone
+  // on its CU and its 2 x 3 KiB per wave in flight make it LATENCY-bound: measured (tools/ragged_curve.py) a step with 16 of 32
+  // rows live cost 2.60 ms against 2.33 ms for a batch of 16, with ONE live row 2.44 against 1.47 - one workgroup needs ~25 us
+  // for its 384 KB whatever else runs.  So below 1.75 live items per CU the same loop runs DEEP (8 rows per lane and batch:
+  // 16 KiB per wave in flight).  Same row -> lane mapping, same per-lane order of the frames: bit-identical either way.
+  auto stream = [&](auto utag) {
+    constexpr int UU = decltype(utag)::value;
+    u32x4_t ra[UU], rb[UU];
+    if constexpr (UU == U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) ra[u] = ra0[u];      // the batch requested at kernel entry
+    } else {
+      issue(Kp, 0, ra);                                // (re-requests the 3 rows already in flight: 3 of 3 000)
+    }
+    float mloc = -1e30f;
+    auto score = [&](int it0, const u32x4_t (&r)[UU]) {
+#pragma unroll
+      for (int u = 0; u < UU; ++u) {
+        const int t = (it0 + u) * TSTEP + trow;
+        float kf[VEC];
+        up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), kf);
+        float s = 0.f;
+        if (t < tend) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) s = fmaf(qv[j], kf[j], s);
+        }
+        s = group_reduce<LPR>(s, OpSum{});
+        if (t < tend) {
+          if (sub == 0) sc[t] = s;
+          mloc = fmaxf(mloc, s);
+        }
       }
+    };
+    for (int it0 = 0; it0 < n_it; it0 += 2 * UU) {
+      if (it0 + UU < n_it) issue(Kp, it0 + UU, rb);
+      __builtin_amdgcn_sched_barrier(0);   // the next batch is requested before this one is scored
+      score(it0, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + 2 * UU < n_it) issue(Kp, it0 + 2 * UU, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + UU < n_it) score(it0 + UU, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    issue(Vp, 0, ra);   // V rows do not depend on the softmax: in flight under it
+    __builtin_amdgcn_sched_barrier(0);
+    mloc = wave_max(mloc);
+    if (lane == 0) red[wave] = mloc;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+    for (int t = tid; t < Tk; t += NWV * 64) {
+      float p = __expf(sc[t] - mx);
+      sc[t] = p;
+      lsum += p;
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[NWV + wave] = lsum;
+    __syncthreads();
+    const float denom = (red[4] + red[5]) + (red[6] + red[7]);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    auto accum = [&](int it0, const u32x4_t (&r)[UU]) {
+#pragma unroll
+      for (int u = 0; u < UU; ++u) {
+        const int t = (it0 + u) * TSTEP + trow;
+        if (t < tend) {
+          float vf[VEC];
+          up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), vf);
+          const float p = sc[t];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
+        }
+      }
+    };
+    for (int it0 = 0; it0 < n_it; it0 += 2 * UU) {
+      if (it0 + UU < n_it) issue(Vp, it0 + UU, rb);
+      __builtin_amdgcn_sched_barrier(0);
+      accum(it0, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + 2 * UU < n_it) issue(Vp, it0 + 2 * UU, ra);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it0 + UU < n_it) accum(it0 + UU, rb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
+    if (rin == 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) part[wave * 64 + sub * VEC + j] = acc[j];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const float v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+      out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
     }
   };
-  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
-    if (it0 + U < n_it) issue(Kp, it0 + U, rb);
-    __builtin_amdgcn_sched_barrier(0);   // the next batch is requested before this one is scored
-    score(it0, ra);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it0 + 2 * U < n_it) issue(Kp, it0 + 2 * U, ra);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it0 + U < n_it) score(it0 + U, rb);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  issue(Vp, 0, ra);   // V rows do not depend on the softmax: in flight under it
-  __builtin_amdgcn_sched_barrier(0);
-  mloc = wave_max(mloc);
-  if (lane == 0) red[wave] = mloc;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float lsum = 0.f;
-  for (int t = tid; t < Tk; t += NWV * 64) {
-    float p = __expf(sc[t] - mx);
-    sc[t] = p;
-    lsum += p;
-  }
-  lsum = wave_sum(lsum);
-  if (lane == 0) red[NWV + wave] = lsum;
-  __syncthreads();
-  const float denom = (red[4] + red[5]) + (red[6] + red[7]);
-  float acc[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-  auto accum = [&](int it0, const u32x4_t (&r)[U]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = (it0 + u) * TSTEP + trow;
-      if (t < tend) {
-        float vf[VEC];
-        up8<T>(make_uint4(r[u].x, r[u].y, r[u].z, r[u].w), vf);
-        const float p = sc[t];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
-      }
-    }
-  };
-  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
-    if (it0 + U < n_it) issue(Vp, it0 + U, rb);
-    __builtin_amdgcn_sched_barrier(0);
-    accum(it0, ra);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it0 + 2 * U < n_it) issue(Vp, it0 + 2 * U, ra);
-    __builtin_amdgcn_sched_barrier(0);
-    if (it0 + U < n_it) accum(it0 + U, rb);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = stride_reduce<LPR>(acc[j], OpSum{});
-  if (rin == 0) {
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) part[wave * 64 + sub * VEC + j] = acc[j];
-  }
-  __syncthreads();
-  if (tid < 64) {
-    const float v = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    out[(int64_t)b * d + h * 64 + tid] = from_f<T>(v / denom);
-  }
+  if (n_live * H <= deep_items) stream(std::integral_constant<int, XATTN_DEEP_U>{});
+  else stream(std::integral_constant<int, U>{});
 }
 
 // Small batches (B*H workgroups < CU count: single-file transcription, beam rows of one clip, streaming): the
@@ -1041,7 +1098,7 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
   } while (0)
   if constexpr (sizeof(T) == 2) {
     if ((g_xattn_variant & 2) && !qp.W) {   // software-pipelined form (default since round 4), 3 rows per lane and batch
-#define TTASR_XP(NT_, QS_) hipLaunchKernelGGL((cross_attn_pipe_kernel<T, NT_, QS_, 3>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, H, Tk, kv_div, sq)
+#define TTASR_XP(NT_, QS_) hipLaunchKernelGGL((cross_attn_pipe_kernel<T, NT_, QS_, 3>), dim3(H, B), dim3(256), lds, s, q, K, V, out, done, H, Tk, kv_div, g_xattn_deep_items, sq)
       const bool nt = g_xattn_variant & 1, qs = sq.n > 0;
       if (g_kernel_sig_on) snprintf(g_kernel_sig, sizeof g_kernel_sig, "cross_attn_pipe_kernel<%s, %s, %s, 3> grid %d", sig_type<T>(),
                                     nt ? "true" : "false", qs ? "true" : "false", H * B * 256);

@@ -96,7 +96,9 @@ def test_shared_context_costs_no_weights_and_computes_the_same():
     assert conc["d"][1] == serial["b"][1]
     twin.close()
     torch.cuda.synchronize()
-    assert _free() >= f0 - (64 << 20), (f0, _free())                    # everything came back (allocator slack aside)
+    # everything came back: arenas are 64 MiB / 1 GiB blocks, so a context (or a weight copy) left behind would hold >= 0.5 GB;
+    # what stays is the HIP runtime's one-off state of this process (code objects, queues, graph pools: measured 226 MB)
+    assert _free() >= f0 - (400 << 20), (f0, _free())
 
 
 def _files(n):
@@ -119,9 +121,9 @@ def test_pipelined_folder_path_equals_the_serial_one_file_by_file():
     kw = dict(language="zh", beam_size=5, temperature=0.0, log_prob_threshold=None, compression_ratio_threshold=None,
               no_speech_threshold=None, max_new_tokens=24)
     m = WhisperModel("synthetic:large-v3-w2", device="cuda", compute_type="bfloat16", max_batch=10, pipeline_depth=2)
-    f_before = _free()
     serial = m.transcribe_groups(groups, pipeline_depth=1, **kw)
-    assert len(m._lanes) == 1 and _free() >= f_before - (8 << 20)             # depth 1 never builds a second context
+    assert len(m._lanes) == 1                                                  # depth 1 never builds a second context
+    f_before = _free()                                                         # (after lane 0's first-use allocations: graphs, scratch)
     piped = m.transcribe_groups(groups, **kw)                                  # the model's own depth: 2
     assert len(m._lanes) == 2 and m._lanes[1].shares_weights
     lane_cost = f_before - _free()
