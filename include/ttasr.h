@@ -237,7 +237,7 @@ TTASR_API int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32
  * "enc_gemm" [0] = 1 | 2 | 3 | 4 forces one encoder GEMM kernel; "enc_gemm_persistent" [1] persistent 256x256 GEMM workgroups (bit-identical to the one-tile-per-workgroup form); "dec_narrow_blocks" [1] 20-row n-blocks in the packed decode matrix whose 20-row block count is a multiple of the 256 CUs (large-v3 family: fc1 = 256 workgroups instead of 160; a weight LAYOUT choice: set it before the first ttasr_load_tensor, later changes are refused); "enc_ln_defer" [1] one f32 read-modify-write of the encoder's residual stream per layer instead of two (bit-identical); "enc_gemm_tail" [1] the persistent GEMM's last partial round of workgroups re-tiled with 192- / 128-row tiles where the plan beats the plain tiling (bit-identical); "xkv_grouped" [1] the cross-KV projections of all decoder layers as ONE grouped launch of that kernel (bit-identical to one launch per layer); "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =
  * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "xattn_pipeline" [1] (software-pipelined cross-attention), "weights_nontemporal" [1] (all per context
  * since round 4); "ragged_exit" [1] finished rows of a decode batch leave its attention kernels (0: static batch, every row
- * streams its cross-KV until the last one ends; live rows are bit-identical either way); "xattn_deep_items" [448] live (row, head)
+ * streams its cross-KV until the last one ends; live rows are bit-identical either way); "xattn_deep_items" [512] live (row, head)
  * items at or below which the decode step's cross-attention workgroups keep 8 instead of 3 rows per lane in flight (0: never;
  * bit-identical);
  * "enc_kernel_timing" [0] per-launch events in ttasr_encode (see ttasr_encoder_kernel_ms); "xkv_fp8" [0] (16-bit engines; opt-in serving
@@ -250,6 +250,11 @@ TTASR_API int ttasr_set_option(ttasr_ctx* ctx, const char* key, int32_t value);
 /* hipEvent times (ms) of the last log_mel / encode (stem+layers, cross-KV) / generate calls:
  * out[0]=mel out[1]=encoder out[2]=cross_kv out[3]=decode. */
 TTASR_API int ttasr_phase_ms(ttasr_ctx* ctx, float out_ms[4]);
+/* Host-side split of the LAST beam search on this context (ms): out[0] enqueueing (copies, launches), out[1] waiting for the GPU
+ * (the one stream synchronisation per searching position), out[2] candidate selection + page bookkeeping on the host, out[3] =
+ * number of positions stepped (a count, not ms).  The search is position-synchronous with the candidate rule on the host
+ * (C++ inside the library); this is what that costs. */
+TTASR_API int ttasr_beam_profile(ttasr_ctx* ctx, float out_ms[4]);
 /* Where the encoder phase went, IN SITU: with option "enc_kernel_timing" = 1 the next ttasr_encode records one hipEvent after
  * every launch of its schedule (not an isolated relaunch loop: each kernel runs between its real neighbours) and this call
  * returns the per-class sums of that pass in ms: out[0] conv stem, [1] LayerNorms, [2] qkv GEMMs, [3] attention, [4] out-proj

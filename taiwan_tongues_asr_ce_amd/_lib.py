@@ -15,7 +15,7 @@ SYMBOLS = [
     "ttasr_create", "ttasr_create_shared", "ttasr_destroy", "ttasr_last_error", "ttasr_version", "ttasr_load_tensor", "ttasr_load_tensor_device",
     "ttasr_finalize_weights", "ttasr_log_mel", "ttasr_log_mel_windows", "ttasr_set_mel", "ttasr_encode", "ttasr_set_encoder_output",
     "ttasr_get_cross_kv", "ttasr_set_audio_ctx", "ttasr_generate", "ttasr_generate_capped", "ttasr_generate_beam", "ttasr_generate_beam_ragged", "ttasr_generate_sample", "ttasr_decode_reset", "ttasr_decode_step", "ttasr_apply_rules", "ttasr_align", "ttasr_dtw",
-    "ttasr_set_option", "ttasr_phase_ms", "ttasr_encoder_kernel_ms", "ttasr_bench_kernel", "ttasr_bench_kernel_signature", "ttasr_sync",
+    "ttasr_set_option", "ttasr_phase_ms", "ttasr_beam_profile", "ttasr_encoder_kernel_ms", "ttasr_bench_kernel", "ttasr_bench_kernel_signature", "ttasr_sync",
 ]
 
 
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     lib.ttasr_dtw.argtypes = [f32p, i32, i32, i32p, i32p, i32p]
     lib.ttasr_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.ttasr_phase_ms.argtypes = [vp, f32p]
+    lib.ttasr_beam_profile.argtypes = [vp, f32p]
     lib.ttasr_encoder_kernel_ms.argtypes = [vp, f32p]
     lib.ttasr_bench_kernel.argtypes = [vp, C.c_char_p, i32, i32, f32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ttasr_sync.argtypes = [vp]

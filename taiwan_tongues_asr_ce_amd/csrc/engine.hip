@@ -16,7 +16,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
-  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; }   // this context's kernel variants for everything f launches
+  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; }   // this context's kernel variants for everything f launches
   g_launch_fault[0] = 0;
   try {
     const int rc = f();
@@ -168,6 +168,7 @@ void ttasr_destroy(ttasr_ctx* c) {
   for (auto& e : c->enc_ev) hipEventDestroy(e);
   for (void* p : c->allocs) hipFree(p);
   if (c->pinned_i32) hipHostFree(c->pinned_i32);
+  if (c->pinned_beam) hipHostFree(c->pinned_beam);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   if (owner && owner->sharers.fetch_sub(1) == 1 && owner->destroy_pending) ttasr_destroy(owner);   // we were the last sharer
@@ -540,6 +541,14 @@ int ttasr_apply_rules(ttasr_ctx* c, const float* rows, const int32_t* hist, int3
   if (out_choice) HIPCHK(c, hipMemcpyAsync(out_choice, c->st.cur_tok, n * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());
+  return TTASR_OK;
+  });
+}
+
+int ttasr_beam_profile(ttasr_ctx* c, float out[4]) {
+  return guarded(c, [&]() -> int {
+  if (!c || !out) return TTASR_E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = c->beam_prof_ms[i];
   return TTASR_OK;
   });
 }

@@ -118,11 +118,18 @@ struct ttasr_ctx {
   std::atomic<int> sharers{0};
   bool destroy_pending = false;
   int32_t* row_cap_dev = nullptr;   // [maxB] per-row token budgets (st.row_cap; ttasr_generate_capped), "no budget" = 0x7f7f7f7f
-  int xattn_deep_items = 448;       // option xattn_deep_items: see kernels_attn.hip cross_attn_pipe_kernel (0: never stream deep)
+  int xattn_mq_slices = 0;          // option xattn_mq_slices (A/B): 0 = automatic
+  int xattn_deep_items = 512;       // option xattn_deep_items: see kernels_attn.hip cross_attn_pipe_kernel (0: never stream deep; 512 = 2 per CU: measured optimum, profiles/r6_xattn_deep_sweep.jsonl)
   bool ragged_exit = true;          // option ragged_exit [1]: finished rows (st.done) leave the attention kernels of the decode step
                                     // (0: the static batch of rounds 1-5 - every row streams its cross-KV until the last one ends; A/B)
   RuleDyn* rule_dyn_dev = nullptr; RuleDyn rule_dyn_host{};  // per-window rule scalars read by select_kernel (common.hpp RuleDyn)
   int32_t* pinned_i32 = nullptr;  // host pinned scratch
+  // beam search (round 6): every per-position host <-> device exchange goes through ONE pinned block - page tables, fed tokens,
+  // row histories and copy-on-write pairs out, top-k candidates back - so the copies are truly asynchronous (a pageable source
+  // makes hipMemcpyAsync stage and block: measured ~0.5 ms of host time per position in round 5's loop) and a searching position
+  // costs ONE stream synchronisation instead of two
+  char* pinned_beam = nullptr; size_t pinned_beam_bytes = 0;
+  float beam_prof_ms[4]{0, 0, 0, 0};   // last beam search: host time enqueueing, waiting for the GPU, selecting candidates; positions
   int max_new_alloc = 0, max_prompt_alloc = 0;
 
   int B_mel = 0, B_enc = 0, B_dec = 0;

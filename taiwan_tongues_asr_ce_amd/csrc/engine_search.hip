@@ -1,6 +1,7 @@
 // libttasr: logits-processor rules, kernel-selection options, greedy / sampled generation and beam search (one of the engine
 // translation units, see engine_ctx.hpp).
 #include "engine_ctx.hpp"
+#include <chrono>
 
 namespace ttasr_detail {
 
@@ -89,10 +90,11 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   }
   else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
   else if (key == "ragged_exit") c->ragged_exit = on;
+  else if (key == "xattn_mq_slices") { if (v < 0 || v > 8) return 1; c->xattn_mq_slices = v; }
   else if (key == "xattn_deep_items") { if (v < 0 || v > 1 << 20) return 1; c->xattn_deep_items = v; }
   else return 1;
   g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0;
-  g_xattn_deep_items = c->xattn_deep_items;
+  g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices;
   drop_graphs(c);
   return 0;
 }
@@ -246,8 +248,25 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
   std::vector<std::vector<int>> seqs(R);
   std::vector<double> sums(R, 0.0);
   std::vector<std::map<std::vector<int>, double>> finished(A);
-  std::vector<float> h_lp((size_t)R * K), h_ns(R, 0.f);
-  std::vector<int32_t> h_id((size_t)R * K), h_state((size_t)4 * R);
+  // the pinned exchange block (engine_ctx.hpp): [page tables R x pps | fed tokens R | row histories 4 R | page pairs 2 R | done R]
+  // out, [log-probs R x K | ids R x K | no-speech R] back
+  const size_t n_up = (size_t)R * pps, o_tok = n_up, o_state = o_tok + R, o_pairs = o_state + 4 * (size_t)R, o_done = o_pairs + 2 * (size_t)R,
+               o_lp = o_done + R, o_id = o_lp + (size_t)R * K, o_ns = o_id + (size_t)R * K, n_words = o_ns + R;
+  if (c->pinned_beam_bytes < n_words * 4) {
+    if (c->pinned_beam) hipHostFree(c->pinned_beam);
+    c->pinned_beam = nullptr; c->pinned_beam_bytes = 0;
+    const size_t want = (size_t)c->maxB * (pps + 8 + 2 * 8 + 1) * 4 + 4096;     // the largest search this context can run
+    HIPCHK(c, hipHostMalloc((void**)&c->pinned_beam, std::max(want, n_words * 4)));
+    c->pinned_beam_bytes = std::max(want, n_words * 4);
+  }
+  int32_t* const pb = (int32_t*)c->pinned_beam;
+  int32_t *const p_up = pb, *const p_tok = pb + o_tok, *const h_state = pb + o_state, *const p_pairs = pb + o_pairs, *const p_done = pb + o_done,
+          *const h_id = pb + o_id;
+  float *const h_lp = (float*)(pb + o_lp), *const h_ns = (float*)(pb + o_ns);
+  for (int r = 0; r < R; ++r) h_ns[r] = 0.f;
+  using clk = std::chrono::steady_clock;
+  double t_enq = 0, t_wait = 0, t_sel = 0; int n_pos = 0;
+  auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
   auto rebuild_free = [&](int upto_idx) {
     std::fill(refcnt.begin(), refcnt.end(), 0);
     for (int r = 0; r < R; ++r)
@@ -291,6 +310,8 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
   bool stop = false;
   for (int pos = pre; pos < c->cfg.n_text_ctx - 1 && !stop; ++pos) {
     // 1. the page this step writes must exist and be private to the row (copy-on-write after a re-index)
+    auto t0 = clk::now();
+    ++n_pos;
     const int j = pos / 16;
     pairs.clear();
     for (int r = 0; r < R; ++r) {
@@ -305,20 +326,6 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
         refcnt[pg]--; refcnt[np] = 1; pg = np;
       }
     }
-    if (!pairs.empty()) {
-      HIPCHK(c, hipMemcpyAsync(c->pairs_dev, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice, s));
-      TT_DISPATCH(c, launch_copy_pages<T>((T*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s));
-    }
-    {  // page tables are stored [row][pps] with unused entries clamped to a valid page id
-      std::vector<int32_t> up(tbl);
-      for (auto& v : up) if (v < 0) v = 0;
-      HIPCHK(c, hipMemcpyAsync(c->page_table, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
-      HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, cur_tok.data(), R * 4, hipMemcpyHostToDevice, s));
-      if (done_dirty) { HIPCHK(c, hipMemcpyAsync(c->st.done, done_rows.data(), (size_t)R * 4, hipMemcpyHostToDevice, s)); done_dirty = false; }
-      HIPCHK(c, hipStreamSynchronize(s));  // `up` is a stack temporary
-    }
-    // 2. one decoder step over the R rows (logits only; the search itself runs on the host)
-    TRY(step_graph(c, R, 1));
     // per clip: still forced through its prompt, searching, or finished
     auto forced_next = [&](int a) { return prompt[(size_t)a * max_prompt + pos + 1]; };
     bool any_sampling = false, any_ns = false;
@@ -326,22 +333,48 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
       any_sampling |= !done[a] && pos + 1 >= plens[a];
       any_ns |= o->no_speech >= 0 && out_ns && pos == sot_of(a);
     }
+    // everything the device needs for this position, staged in the pinned block and copied asynchronously: page tables ([row][pps],
+    // unused entries clamped to a valid page id), the fed tokens, the copy-on-write pairs, finished flags, and - when a clip
+    // searches at this position - the row histories the candidate kernel applies the rules from (host-known before the step)
+    for (size_t i = 0; i < n_up; ++i) p_up[i] = tbl[i] < 0 ? 0 : tbl[i];
+    memcpy(p_tok, cur_tok.data(), (size_t)R * 4);
+    HIPCHK(c, hipMemcpyAsync(c->page_table, p_up, n_up * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->st.cur_tok, p_tok, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    if (!pairs.empty()) {
+      memcpy(p_pairs, pairs.data(), pairs.size() * 4);
+      HIPCHK(c, hipMemcpyAsync(c->pairs_dev, p_pairs, pairs.size() * 4, hipMemcpyHostToDevice, s));
+      TT_DISPATCH(c, launch_copy_pages<T>((T*)c->pool, c->pairs_dev, (int)pairs.size() / 2, c->cfg.dec_layers, c->H, c->pool_layer_elems, s));
+    }
+    if (done_dirty) {
+      memcpy(p_done, done_rows.data(), (size_t)R * 4);
+      HIPCHK(c, hipMemcpyAsync(c->st.done, p_done, (size_t)R * 4, hipMemcpyHostToDevice, s));
+      done_dirty = false;
+    }
+    if (any_sampling || any_ns) {
+      for (int r = 0; r < R; ++r) {
+        int last = -1, pen = -1, lts = -1;
+        for (int t : seqs[r]) { pen = last; last = t; if (t >= o->timestamp_begin) lts = t; }
+        h_state[r] = (int)seqs[r].size(); h_state[R + r] = last; h_state[2 * R + r] = pen; h_state[3 * R + r] = lts;
+      }
+      HIPCHK(c, hipMemcpyAsync(c->row_state, h_state, (size_t)4 * R * 4, hipMemcpyHostToDevice, s));
+    }
+    // 2. one decoder step over the R rows (logits only; the search itself runs on the host) and, behind it, the candidates
+    TRY(step_graph(c, R, 1));
+    if (any_sampling || any_ns) {
+      BeamRowState bs{c->row_state, c->row_state + R, c->row_state + 2 * R, c->row_state + 3 * R, c->mask_dev};
+      launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, any_ns ? c->st.no_speech : nullptr, s);
+      HIPCHK(c, hipMemcpyAsync(h_lp, c->topk_lp, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(c, hipMemcpyAsync(h_id, c->topk_id, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
+      if (any_ns) HIPCHK(c, hipMemcpyAsync(h_ns, c->st.no_speech, (size_t)R * 4, hipMemcpyDeviceToHost, s));
+    }
+    t_enq += ms_since(t0); t0 = clk::now();
+    HIPCHK(c, hipStreamSynchronize(s));   // the ONE synchronisation of the position (also frees the pinned block for the next one)
+    t_wait += ms_since(t0); t0 = clk::now();
+    struct Sel { double& acc; clk::time_point t0; ~Sel() { acc += std::chrono::duration<double, std::milli>(clk::now() - t0).count(); } } sel_timer{t_sel, t0};
     if (!any_sampling && !any_ns) {
       for (int r = 0; r < R; ++r) cur_tok[r] = done[r / beam] ? o->eot : forced_next(r / beam);
       continue;
     }
-    for (int r = 0; r < R; ++r) {
-      int last = -1, pen = -1, lts = -1;
-      for (int t : seqs[r]) { pen = last; last = t; if (t >= o->timestamp_begin) lts = t; }
-      h_state[r] = (int)seqs[r].size(); h_state[R + r] = last; h_state[2 * R + r] = pen; h_state[3 * R + r] = lts;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->row_state, h_state.data(), (size_t)4 * R * 4, hipMemcpyHostToDevice, s));
-    BeamRowState bs{c->row_state, c->row_state + R, c->row_state + 2 * R, c->row_state + 3 * R, c->mask_dev};
-    launch_beam_topk(c->logits, bs, c->rp, R, K, c->topk_lp, c->topk_id, any_ns ? c->st.no_speech : nullptr, s);
-    HIPCHK(c, hipMemcpyAsync(h_lp.data(), c->topk_lp, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(h_id.data(), c->topk_id, (size_t)R * K * 4, hipMemcpyDeviceToHost, s));
-    if (any_ns) HIPCHK(c, hipMemcpyAsync(h_ns.data(), c->st.no_speech, R * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
     for (int a = 0; a < A; ++a)
       if (o->no_speech >= 0 && out_ns && pos == sot_of(a)) ns_final[a] = h_ns[a * beam];
     if (!any_sampling) {
@@ -404,6 +437,7 @@ int beam_search_impl(ttasr_ctx* c, int32_t A, int32_t beam, const int32_t* promp
     if (all_done) stop = true;
   }
   hipEventRecord(c->ev[6], s);
+  c->beam_prof_ms[0] = (float)t_enq; c->beam_prof_ms[1] = (float)t_wait; c->beam_prof_ms[2] = (float)t_sel; c->beam_prof_ms[3] = (float)n_pos;
   HIPCHK(c, hipMemsetAsync(c->st.done, 0, (size_t)R * 4, s));   // the flags belong to THIS search
   HIPCHK(c, hipStreamSynchronize(s));
   HIPCHK(c, hipGetLastError());

@@ -558,8 +558,9 @@ __global__ __launch_bounds__(NWV * 64) void cross_attn_decode_kernel(const T* q,
 // 2 43.8 (tools/microbench/xattn_bench.hip, profiles/r4_xattn_pipeline.txt).  At a balanced 2.97 workgroups per CU (B = 38) every
 // form runs 6.42-6.48 TB/s: the gain at B = 32 is a shorter tail of the uneven 3-vs-2 workgroup split, not a faster stream.
 // 16-bit storage, 4 waves, decode step only (no PROBS).
-thread_local int g_xattn_deep_items = 448;   // option xattn_deep_items: live (row, head) items at or below which a workgroup streams
-                                             // DEEP (default 1.75 per CU of 256; 0 = never) - per context, like g_xattn_variant
+thread_local int g_xattn_mq_slices = 0;     // option xattn_mq_slices (A/B): frame slices of the shared-clip cross-attention, 0 = automatic
+thread_local int g_xattn_deep_items = 512;   // option xattn_deep_items: live (row, head) items at or below which a workgroup streams
+                                             // DEEP (default 2 per CU of 256 - sweep: 448 loses 0.08 ms per step at 24 live rows, 576 costs 0.15 ms at 26-28; 0 = never) - per context, like g_xattn_variant
 constexpr int XATTN_DEEP_U = 8;              // rows per lane and batch of the deep form
 template <typename T, bool NT, bool QSLAB, int U>
 __global__ __launch_bounds__(256) void cross_attn_pipe_kernel(const T* q, const T* K, const T* V, T* out, const int32_t* done, int H,
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
                                                             int kv_div, int groups, int nq_last, T* __restrict__ out,
                                                             const int32_t* __restrict__ done) {
   constexpr int VEC = RowVec<T>::VEC, LPR = 64 / VEC, RPI = 64 / LPR;
-  constexpr int UNROLL = NQ <= 4 ? 8 : 4;
+  constexpr int PIPE_U = NQ <= 5 ? 6 : 4;   // rows per lane and batch (two batches in flight); registers: NQ x 16 + PIPE_U x 8 + ...
   extern __shared__ float sc[];  // [NQ][chunk] scores, then [4][NQ][64] partial outputs, [2][NQ][4] reductions
   const int h = blockIdx.x, z = blockIdx.z, S = gridDim.z;
   const int clip = blockIdx.y / groups, grp = blockIdx.y - clip * groups;
@@ -908,15 +909,27 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   const T* Kp = K + (((int64_t)clip * H + h) * Tk + t0) * 64;
   const T* Vp = V + (((int64_t)clip * H + h) * Tk + t0) * 64;
   const int n_it = (n + 4 * RPI - 1) / (4 * RPI);
-  float kv[UNROLL][VEC];
-  auto load_rows = [&](const T* base, int it0) {
+  // Round 6: the K (then V) stream is software-pipelined like cross_attn_pipe_kernel - two register sets of U rows per lane, batch
+  // i + 1 requested before batch i is scored, the first V batch before the softmax.  The one-batch-at-a-time form left a
+  // workgroup with nothing in flight while it scored 5-8 queries against every row: 22.4 us per layer for the 61 MB of 8 clips
+  // (2.7 TB/s) plus a 5 us merge launch - 30 % of a beam-5 step (profiles/r6_beam5_8clips_nograph_kernel_stats.csv).
+  constexpr int U = PIPE_U;
+  typedef typename std::conditional<sizeof(T) == 2, u32x4_t, float4>::type raw_t;   // one 16-byte chunk of a row, as loaded
+  auto issue = [&](const T* base, int it0, raw_t (&r)[U]) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int t = ((it0 + u) * 4 + wave) * RPI + rin;
-      RowVec<T>::load(base + (int64_t)min(t, n - 1) * 64 + sub * VEC, kv[u]);  // clamped, unconditional
+      const T* p = base + (int64_t)min(t, n - 1) * 64 + sub * VEC;   // clamped, unconditional
+      if constexpr (sizeof(T) == 2) r[u] = __builtin_nontemporal_load((const u32x4_t*)p);
+      else r[u] = *(const float4*)p;
     }
   };
-  load_rows(Kp, 0);  // the stream starts before the queries are fetched
+  auto unpack = [&](const raw_t& r, float (&v)[VEC]) {
+    if constexpr (sizeof(T) == 2) up8<T>(make_uint4(r.x, r.y, r.z, r.w), v);
+    else { v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w; }
+  };
+  raw_t ra[U], rb[U];
+  issue(Kp, 0, ra);  // the stream starts before the queries are fetched
   float qv[NQ][VEC];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
@@ -927,16 +940,17 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   float mloc[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) mloc[qi] = -1e30f;
-  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    if (it0 > 0) load_rows(Kp, it0);
+  auto score = [&](int it0, const raw_t (&r)[U]) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int t = ((it0 + u) * 4 + wave) * RPI + rin;
+      float kf[VEC];
+      unpack(r[u], kf);
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) s = fmaf(qv[qi][j], kv[u][j], s);
+        for (int j = 0; j < VEC; ++j) s = fmaf(qv[qi][j], kf[j], s);
         s = group_reduce<LPR>(s, OpSum{});
         if (t < n) {
           if (sub == 0) sc[qi * chunk + t] = s;
@@ -944,8 +958,19 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
         }
       }
     }
+  };
+  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
+    if (it0 + U < n_it) issue(Kp, it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);   // the next batch is requested before this one is scored
+    score(it0, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + 2 * U < n_it) issue(Kp, it0 + 2 * U, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + U < n_it) score(it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  load_rows(Vp, 0);  // V rows do not depend on the softmax: requested before it
+  issue(Vp, 0, ra);  // V rows do not depend on the softmax: requested before it
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     const float m = wave_max(mloc[qi]);
@@ -977,20 +1002,31 @@ __global__ __launch_bounds__(256) void cross_attn_mq_kernel(const T* __restrict_
   for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[qi][j] = 0.f;
-  for (int it0 = 0; it0 < n_it; it0 += UNROLL) {
-    if (it0 > 0) load_rows(Vp, it0);
+  auto accum = [&](int it0, const raw_t (&r)[U]) {
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int t = ((it0 + u) * 4 + wave) * RPI + rin;
       if (t < n) {
+        float vf[VEC];
+        unpack(r[u], vf);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) {
           const float p = sc[qi * chunk + t];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[qi][j] = fmaf(p, kv[u][j], acc[qi][j]);
+          for (int j = 0; j < VEC; ++j) acc[qi][j] = fmaf(p, vf[j], acc[qi][j]);
         }
       }
     }
+  };
+  for (int it0 = 0; it0 < n_it; it0 += 2 * U) {
+    if (it0 + U < n_it) issue(Vp, it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
+    accum(it0, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + 2 * U < n_it) issue(Vp, it0 + 2 * U, ra);
+    __builtin_amdgcn_sched_barrier(0);
+    if (it0 + U < n_it) accum(it0 + U, rb);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
@@ -1046,7 +1082,11 @@ void launch_cross_attn_decode(const T* q, const T* K, const T* V, T* out, int B,
   if (split_ws && kv_div >= 2 && B % kv_div == 0 && B * H >= 256) {  // split_ws == nullptr: the caller asked for per-row kernels
     const int A = B / kv_div;
     const int NQ = kv_div < 8 ? kv_div : 8, groups = (kv_div + NQ - 1) / NQ, nq_last = kv_div - (groups - 1) * NQ;
-    const int Sq = cross_attn_splits(A * groups, H, Tk);
+    // frame slices per group (option xattn_mq_slices, 0 = the automatic rule of cross_attn_splits).  ONE slice per group - no
+    // workspace, no merge launch - was measured with the pipelined stream and is SLOWER at 8 clips x beam 5 (160 workgroups,
+    // one per CU: 2.98 vs 2.74 ms per step): a lone workgroup scores 5 queries against every row on one wave per SIMD.
+    int Sq = cross_attn_splits(A * groups, H, Tk);
+    if (g_xattn_mq_slices > 0) Sq = g_xattn_mq_slices > 8 ? 8 : g_xattn_mq_slices;
     const int chunk = ((Tk + Sq - 1) / Sq + 31) / 32 * 32;
     const int S2 = (Tk + chunk - 1) / chunk;  // every slice non-empty; S2 <= 8
     const size_t lds = sizeof(float) * ((size_t)NQ * chunk + 4 * NQ * 64 + 8 * NQ);

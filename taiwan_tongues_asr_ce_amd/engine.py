@@ -330,6 +330,12 @@ class Engine:
         self._check(self.lib.ttasr_phase_ms(self.h, a), "phase_ms")
         return dict(mel=a[0], encoder=a[1], cross_kv=a[2], decode=a[3])
 
+    def beam_profile(self) -> Dict[str, float]:
+        """Host-side split of the last beam search (ttasr_beam_profile): ms enqueueing / waiting for the GPU / selecting, positions."""
+        a = (C.c_float * 4)()
+        self._check(self.lib.ttasr_beam_profile(self.h, a), "beam_profile")
+        return dict(enqueue_ms=a[0], gpu_wait_ms=a[1], host_select_ms=a[2], positions=int(a[3]))
+
     def encoder_kernel_ms(self) -> Dict[str, float]:
         """Per-class in-situ times of the last encode() run with option enc_kernel_timing = 1 (ttasr_encoder_kernel_ms)."""
         a = (C.c_float * 8)()

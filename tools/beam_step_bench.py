@@ -50,6 +50,7 @@ def main():
         n_steps = max(len(t) for t in toks) + len(prompt)
         print(json.dumps({"clips": A, "beam": args.beam, "rows": A * args.beam, "wall_ms": round(min(ms[1:]), 2),
                           "steps_upper_bound": n_steps, "ms_per_step": round(min(ms[1:]) / n_steps, 3),
+                          "host_split_last_run": {k: round(v, 2) for k, v in e.beam_profile().items()},
                           "options": args.option}), flush=True)
         e.close()
 
