@@ -627,7 +627,7 @@ def main():
         # matrix-pipe occupancy of the same four kernels from the committed PMC pass (clock-independent; static, like traffic)
         pmc_busy, pmc_file, pmc_note = None, None, None
         try:
-            pmc_file = next(f_ for f_ in ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
+            pmc_file = next(f_ for f_ in ("r6_pmc.json", "r5_pmc.json", "r4_pmc.json", "r3_pmc.json", "r2_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", f_)))
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc_busy, pmc_note = pmc_busy_from_profile(json.load(f)["kernels"], [x.get("signature") for x in gs], [x["flops"] for x in gs])
         except Exception as ex:
@@ -803,6 +803,38 @@ def main():
                 side["f16"] = m
                 e3.close()
                 engines.remove(e3)
+            if not args.no_side and args.compute == "bf16" and not args.xkv_fp8 and args.model == "large-v3":
+                # folder: the reference's folder tool (asr_core.py:151: one file at a time) on 12 synthetic recordings of 60 s, beam 5,
+                # <= 64 tokens per 30-s window, through WhisperModel - groups of 6 files in lock step, ONE group at a time
+                # (pipeline_depth 1) against TWO groups in flight on two engine contexts that share one copy of the weights
+                # (pipeline_depth 2: round 6).  Same groups -> identical results; audio-s/s = 720 s of audio / wall time.
+                for e_ in list(engines):          # the model below builds its own contexts: release the bench engine's 20 GB first
+                    e_.close()
+                engines.clear()
+                import warnings
+                from taiwan_tongues_asr_ce_amd.model import WhisperModel
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    wm = WhisperModel(f"synthetic:{args.model}", device="cuda", device_index=local, compute_type="bfloat16", max_batch=30,
+                                      pipeline_depth=2)
+                    files = [np.concatenate([synth.tonal_clip(2 * i), synth.noise_clip(2 * i + 1)]) for i in range(12)]
+                    groups = [files[:6], files[6:]]
+                    kwf = dict(language="zh", beam_size=5, temperature=0.0, log_prob_threshold=None, max_new_tokens=64)
+                    wm.transcribe_groups(groups, pipeline_depth=2, **kwf)             # warm-up: both lanes, graphs
+                    res, wall = {}, {}
+                    for depth in (1, 2, 1, 2):
+                        ts_ = time.perf_counter()
+                        r_ = wm.transcribe_groups(groups, pipeline_depth=depth, **kwf)
+                        wall[depth] = min(wall.get(depth, 1e9), time.perf_counter() - ts_)
+                        res[depth] = [[(sg.start, sg.end, tuple(sg.tokens)) for sg in segs] for g_ in r_ for segs, _ in g_]
+                    side["folder"] = {
+                        "workload": "12 x 60 s synthetic recordings, beam 5, <= 64 tokens per window, 6 files in lock step per group",
+                        "serial_audio_s_per_s": round(720.0 / wall[1], 1), "pipelined_audio_s_per_s": round(720.0 / wall[2], 1),
+                        "serial_s": round(wall[1], 3), "pipelined_s": round(wall[2], 3), "speed_up": round(wall[1] / wall[2], 3),
+                        "results_identical": res[1] == res[2], "engine_contexts": len(wm._lanes),
+                        "second_context_shares_weights": bool(wm._lanes[1].shares_weights),
+                        "note": "WhisperModel(..., pipeline_depth=2).transcribe_groups / batch_cli --pipeline-depth 2 (ttasr_create_shared)"}
+                    wm.close()
             out["side"] = side
         if world == 1 and not args.no_cpu_baseline:
             # cpu_baseline.value = ONE COMPLETE run of the CPU oracle on one clip of the workload, executed live on this box's host

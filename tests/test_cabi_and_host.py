@@ -389,3 +389,64 @@ def test_bench_reports_pmc_numbers_only_for_the_kernel_signature_they_were_taken
     import json
     xp_now = json.load(open(os.path.join(ROOT, "profiles", "xattn_pmc.json")))
     assert xp_now.get("signatures"), "profiles/xattn_pmc.json predates the signature check: refresh it (tools/gpu_session.sh)"
+
+
+def test_transcribe_groups_lanes_threads_and_errors():
+    """Round 6: `WhisperModel.transcribe_groups` runs the groups on `pipeline_depth` worker threads, each bound to its own
+    engine lane (lane 0 owns the weights, the others are created with share_weights_with=lane 0 on first use); results come back in
+    group order, an exception inside a lane surfaces on the caller's thread, and depth 1 touches neither threads nor lanes."""
+    import threading
+    import time
+
+    class _LaneEngine:
+        made = []
+
+        def __init__(self, *args, share_weights_with=None):
+            self.owner = share_weights_with
+            self.closed = False
+            _LaneEngine.made.append(self)
+
+        def close(self):
+            self.closed = True
+
+    m = _bare_model()
+    m._engine_ctor, m._engine_args, m.pipeline_depth = _LaneEngine, (), 2
+    m.engine = _LaneEngine()                       # lane 0 through the test setter
+    seen = []
+
+    def fake_many(group, **kw):
+        seen.append((threading.current_thread().name, m.engine, tuple(group)))
+        time.sleep(0.05 if group[0] % 2 == 0 else 0.01)         # groups finish out of order
+        if group[0] < 0:
+            raise RuntimeError("lane fault")
+        return [("segments of", g) for g in group]
+    m.transcribe_many = fake_many
+    groups = [[0, 1], [2, 3], [4], [6, 7], [9]]
+    out = m.transcribe_groups(groups, pipeline_depth=1)
+    assert out == [[("segments of", g) for g in grp] for grp in groups]
+    assert len(m._lanes) == 1 and all(t == threading.current_thread().name and e is m._lanes[0] for t, e, _ in seen)
+    seen.clear()
+    out2 = m.transcribe_groups(groups)                                       # the model's depth: 2
+    assert out2 == out                                                       # group order, whatever finished first
+    assert len(m._lanes) == 2 and m._lanes[1].owner is m._lanes[0] and m._lanes[0].owner is None
+    by_thread = {}
+    for t, e, g in seen:
+        by_thread.setdefault(t, set()).add(id(e))
+    assert set(by_thread) == {"ttasr-lane0", "ttasr-lane1"} and all(len(v) == 1 for v in by_thread.values())   # one engine per thread
+    assert {e for t, e, g in seen if t == "ttasr-lane1"} == {m._lanes[1]}
+    assert m.engine is m._lanes[0]                                            # the caller's thread still drives lane 0
+    with pytest.raises(RuntimeError, match="lane fault"):
+        m.transcribe_groups([[0], [-1], [2], [4]])
+    assert m.transcribe_groups(groups[:2]) == out[:2]                         # usable afterwards
+    m.close()
+    assert all(e.closed for e in _LaneEngine.made[:2]) and m._lanes == []
+
+    class _NoShare:
+        def __init__(self, *args):
+            pass
+    m2 = _bare_model()
+    m2._engine_ctor, m2._engine_args, m2.pipeline_depth = _NoShare, (), 2
+    m2.engine = _NoShare()
+    m2.transcribe_many = lambda group, **kw: list(group)
+    with pytest.raises(RuntimeError, match="needs the HIP engine"):
+        m2.transcribe_groups([[1], [2]])

@@ -4,7 +4,7 @@
 #   the kernels it launches), and the side lines (fp16, fp8 cross-KV, other geometries).  Everything lands under gpurun_out/session/.
 set -x
 cd $GRAFT_REPO_ROOT
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 O=$GRAFT_REPO_ROOT/gpurun_out/session; mkdir -p $O
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
