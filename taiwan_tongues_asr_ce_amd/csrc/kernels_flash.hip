@@ -28,13 +28,19 @@ __device__ __forceinline__ s16x4_t lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 
-constexpr int FA_QB = 128, FA_KB = 64;
+constexpr int FA_KB = 64;   // keys per tile; a workgroup = 4 waves x QW blocks of 32 queries (QW = 1: 128 queries, QW = 2: 256)
 
 // CROSS = false: encoder self-attention, q / k / v rows interleaved in one [B][Tn][3d] tensor (n_k == Tn).
 // CROSS = true: the decoder's cross-attention for MANY query rows per clip (a prompt prefill pass): q = [clip][Tn][d] rows, K / V
 // from the cross-KV cache [clip][head][n_k][64] - the clip's frames are streamed once for all of its prompt positions.
-template <typename T16, bool CROSS>
-__global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
+// QW = query blocks of 32 per WAVE (round 6).  With one block (rounds 1-5) every wave re-reads the whole 16 KB K / V tile from LDS
+// for its 32 queries: per wave and tile 16 KB of LDS reads stand against 16 MFMAs of 32 cycles - with four SIMDs sharing one LDS
+// port (128 B per cycle) the LDS reads of a round of four wave-tiles take as long as its MFMAs (512 cycles each), which is why the
+// kernel sat at 0.33 of the MFMA peak with 35 % of its wave cycles stalled (profiles/r5_flash_pmc.txt).  With TWO blocks a wave
+// feeds every K / V fragment it reads to two MFMAs (LDS bytes per flop halve), and the softmax VALU work of one block runs while the
+// other block's MFMAs are in flight: independent chains INSIDE a wave instead of three waves per SIMD arbitrating for the pipe.
+template <typename T16, bool CROSS, int QW>
+__global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
                                                              int H, const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx,
                                                              int n_k_cross) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (K 8 KiB | V 8 KiB); reused for the O transpose
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     qb = slot % nq;
     bh = (slot / nq) * 8 + xcd;
   }
-  const int b = bh / H, h = bh - b * H, q0 = qb * FA_QB + wave * 32;
+  const int b = bh / H, h = bh - b * H, q0 = qb * (128 * QW) + wave * (32 * QW);   // this wave's first query; block w: q0 + 32 w
   const int d = H * 64;
   const int64_t ld = CROSS ? (int64_t)d : 3 * (int64_t)d;                      // query row stride
   const bf16_t* base = qkv + (int64_t)b * Tn * ld + h * 64;                     // query rows of (b, h)
@@ -65,9 +71,10 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   // rounding of q to the storage type (relative 2^-9 / 2^-11, random per element like the rounding q already carries from
   // the qkv GEMM's epilogue); the exact 1/8 pre-scaling stays in the weights.
   constexpr float LOG2E = 1.4426950408889634f;
-  s16x8 qf[4];
-  {
-    const bf16_t* qp = base + (int64_t)min(q0 + r, Tn - 1) * ld + 8 * hf;
+  s16x8 qf[QW][4];
+#pragma unroll
+  for (int w = 0; w < QW; ++w) {
+    const bf16_t* qp = base + (int64_t)min(q0 + 32 * w + r, Tn - 1) * ld + 8 * hf;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       uint4 t = *(const uint4*)(qp + 16 * ks);
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
       up8<T16>(t, v);
       t.x = N16<T16>::pk(v[0] * LOG2E, v[1] * LOG2E); t.y = N16<T16>::pk(v[2] * LOG2E, v[3] * LOG2E);
       t.z = N16<T16>::pk(v[4] * LOG2E, v[5] * LOG2E); t.w = N16<T16>::pk(v[6] * LOG2E, v[7] * LOG2E);
-      qf[ks] = __builtin_bit_cast(s16x8, t);
+      qf[w][ks] = __builtin_bit_cast(s16x8, t);
     }
   }
   // a wave whose 32 queries all lie past the end of the sequence (the last q-block of T = 1500 carries 92 queries: wave 3 has
@@ -123,11 +130,13 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     }                                                                                                              \
   } while (0)
 
-  f32x16 o[2];
+  f32x16 o[QW][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int w = 0; w < QW; ++w)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[w][i][j] = 0.f;
   // Online softmax with the reference maximum INSIDE the score MFMA (round 5): the accumulator of S^T = K Q^T starts at -m_ref
   // (sinit: 16 registers holding this lane's query's -m_ref), so the MFMA delivers s - m_ref and p = exp2(s - m_ref) costs one
   // v_exp_f32 per element and nothing else.  m_ref follows the running maximum lazily (guide T13): it moves only when a tile's
@@ -136,10 +145,9 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
   // once (T13's hazard), so the result is the exact softmax whatever m_ref is; what changes against the running-maximum form is
   // rounding only (the largest p of a row is no longer exactly 1).
   constexpr float FA_THR = 6.0f;
-  f32x16 sinit;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) sinit[j] = 0.f;
-  float m_ref = 0.f, l_run = 0.f;
+  float m_ref[QW], l_run[QW];   // (the MFMA accumulator's start value -m_ref is splat from m_ref at every tile: 16 moves
+#pragma unroll                 //  per block and tile instead of 16 registers per block held for the whole kernel)
+  for (int w = 0; w < QW; ++w) { m_ref[w] = 0.f; l_run[w] = 0.f; }
 
   const int n_tiles = (n_k + FA_KB - 1) / FA_KB;
   FA_DMA(0, 0);
@@ -162,8 +170,15 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     const char* Kb = smem + cur * 16384;
     const char* Vb = Kb + 8192;
     if (live) {
-    // ---- S^T - m_ref = K Q^T - m_ref : two 32-key blocks ----
-    f32x16 s[2];
+    // ---- S^T - m_ref = K Q^T - m_ref : two 32-key blocks, every K fragment read ONCE for the wave's QW query blocks ----
+    f32x16 s[QW][2];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+      f32x16 si;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) si[j] = -m_ref[w];
+      s[w][0] = si; s[w][1] = si;
+    }
 #pragma unroll
     for (int kb2 = 0; kb2 < 2; ++kb2) {
       const int krow = 32 * kb2 + r;
@@ -171,63 +186,60 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s16x8 kf = *(const s16x8*)(Kb + krow * 128 + (((2 * ks + hf) ^ ksw) << 4));
-        s[kb2] = N16<T16>::mfma32(kf, qf[ks], ks == 0 ? sinit : s[kb2]);
+#pragma unroll
+        for (int w = 0; w < QW; ++w) s[w][kb2] = N16<T16>::mfma32(kf, qf[w][ks], s[w][kb2]);
       }
     }
-    if (LAST) {  // mask keys past the end of the sequence (only the peeled last tile carries this code)
+    uint32_t pf[QW][2][8];  // 16-bit-packed P^T: [block][kb2][2*s' + pair]
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {   // block w's softmax VALU work runs while block w + 1's score MFMAs are still in flight
+      if (LAST) {  // mask keys past the end of the sequence (only the peeled last tile carries this code)
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            int key = kt * FA_KB + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hf;
+            if (key >= n_k) s[w][kb2][j] = -1e30f;
+          }
+      }
+      // ---- this lane's query column: how far above the reference is the tile's maximum? ----
+      float tmax = s[w][0][0];
+#pragma unroll
+      for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, s[w][0][j]);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, s[w][1][j]);
+      tmax = xor32_reduce(tmax, OpMax{});  // v_permlane32_swap: no LDS round trip in the tile loop
+      const bool move = (kt == 0) | (tmax > FA_THR);
+      if (__builtin_amdgcn_ballot_w64(move) != 0) {   // rare after the first tile: move the reference of the queries that need it
+        const float delta = move ? tmax : 0.f;       // exp2(0) = 1 exactly for the others
+        // First tile: o and l are still 0, only the reference moves - and the rescale factor must not be evaluated: a first-tile
+        // maximum below about -128 exp2 units (a large negative per-query score offset, e.g. q bias x mean key of a trained
+        // checkpoint) would make exp2(-tmax) = +inf and 0 * inf = NaN for the whole query row.
+        const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        l_run[w] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { o[w][i][j] *= alpha; s[w][i][j] -= delta; }
+        m_ref[w] += delta;
+      }
+      float psum = 0.f;
 #pragma unroll
       for (int kb2 = 0; kb2 < 2; ++kb2)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          int key = kt * FA_KB + 32 * kb2 + (j & 3) + 8 * (j >> 2) + 4 * hf;
-          if (key >= n_k) s[kb2][j] = -1e30f;
+        for (int j = 0; j < 16; j += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(s[w][kb2][j]);
+          const float p1 = __builtin_amdgcn_exp2f(s[w][kb2][j + 1]);
+          psum += p0 + p1;
+          pf[w][kb2][j >> 1] = N16<T16>::pk(p0, p1);
         }
+      l_run[w] += psum;
     }
-    // ---- this lane's query column: how far above the reference is the tile's maximum? ----
-    float tmax = s[0][0];
-#pragma unroll
-    for (int j = 1; j < 16; ++j) tmax = fmaxf(tmax, s[0][j]);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) tmax = fmaxf(tmax, s[1][j]);
-    tmax = xor32_reduce(tmax, OpMax{});  // v_permlane32_swap: no LDS round trip in the tile loop
-    const bool move = (kt == 0) | (tmax > FA_THR);
-    if (__builtin_amdgcn_ballot_w64(move) != 0) {   // rare after the first tile: move the reference of the queries that need it
-      const float delta = move ? tmax : 0.f;       // exp2(0) = 1 exactly for the others
-      // First tile: o and l are still 0, only the reference moves - and the rescale factor must not be evaluated: a first-tile
-      // maximum below about -128 exp2 units (a large negative per-query score offset, e.g. q bias x mean key of a trained
-      // checkpoint) would make exp2(-tmax) = +inf and 0 * inf = NaN for the whole query row.
-      const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { o[i][j] *= alpha; s[i][j] -= delta; }
-      m_ref += delta;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sinit[j] = -m_ref;
-    }
-    float psum = 0.f;
-    uint32_t pf[2][8];  // 16-bit-packed P^T: [kb2][2*s' + pair]
-#pragma unroll
-    for (int kb2 = 0; kb2 < 2; ++kb2)
-#pragma unroll
-      for (int j = 0; j < 16; j += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(s[kb2][j]);
-        const float p1 = __builtin_amdgcn_exp2f(s[kb2][j + 1]);
-        psum += p0 + p1;
-        pf[kb2][j >> 1] = N16<T16>::pk(p0, p1);
-      }
-    l_run += psum;
 
-    // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 2 d-blocks ----
+    // ---- O^T += V^T P^T : 4 k-steps of 16 keys, 2 d-blocks; every V fragment read ONCE for the QW blocks ----
 #pragma unroll
     for (int ss = 0; ss < 4; ++ss) {
       const int kb2 = ss >> 1, sp = ss & 1;
-      s16x8 pb;
-      {
-        uint4 t = make_uint4(pf[kb2][4 * sp + 0], pf[kb2][4 * sp + 1], pf[kb2][4 * sp + 2], pf[kb2][4 * sp + 3]);
-        pb = __builtin_bit_cast(s16x8, t);
-      }
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
         s16x4_t lo, hi;
@@ -238,7 +250,11 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
           hi = lds_tr16(Vb + row1 * 128 + (((db ^ ((row1 >> 1) & 1)) << 6) | (vg << 5) | (vp4 << 3)));
         }
         s16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[db] = N16<T16>::mfma32(vf, pb, o[db]);
+#pragma unroll
+        for (int w = 0; w < QW; ++w) {
+          const uint4 t = make_uint4(pf[w][kb2][4 * sp + 0], pf[w][kb2][4 * sp + 1], pf[w][kb2][4 * sp + 2], pf[w][kb2][4 * sp + 3]);
+          o[w][db] = N16<T16>::mfma32(vf, __builtin_bit_cast(s16x8, t), o[w][db]);
+        }
       }
     }
     }  // live
@@ -259,43 +275,57 @@ __global__ __launch_bounds__(256) void enc_attn_flash_kernel(const bf16_t* __res
     tile(kt, B0{}, std::true_type{});
   }
 
-  // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B ----
-  const float l_tot = xor32_reduce(l_run, OpSum{});
-  const float inv = 1.0f / l_tot;
-  char* ob = smem + wave * (32 * 144);  // [32 q][64 d] bf16, row stride 144 B (128 + 16 pad)
+  // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B (one block at a time) ----
+  char* ob = smem + wave * (32 * 144);  // [32 q][64 d] bf16, row stride 144 B (128 + 16 pad); wave-private
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int w = 0; w < QW; ++w) {
+    const float l_tot = xor32_reduce(l_run[w], OpSum{});
+    const float inv = 1.0f / l_tot;
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      uint2 pk;
-      pk.x = N16<T16>::pk(o[db][4 * rg + 0] * inv, o[db][4 * rg + 1] * inv);
-      pk.y = N16<T16>::pk(o[db][4 * rg + 2] * inv, o[db][4 * rg + 3] * inv);
-      const int dcol = 32 * db + 8 * rg + 4 * hf;
-      *(uint2*)(ob + r * 144 + dcol * 2) = pk;
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        uint2 pk;
+        pk.x = N16<T16>::pk(o[w][db][4 * rg + 0] * inv, o[w][db][4 * rg + 1] * inv);
+        pk.y = N16<T16>::pk(o[w][db][4 * rg + 2] * inv, o[w][db][4 * rg + 3] * inv);
+        const int dcol = 32 * db + 8 * rg + 4 * hf;
+        *(uint2*)(ob + r * 144 + dcol * 2) = pk;
+      }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int id = it * 64 + lane, row = id >> 3, c = id & 7;
+      if (q0 + 32 * w + row < Tn) {
+        uint4 v = *(const uint4*)(ob + row * 144 + c * 16);
+        *(uint4*)(out + ((int64_t)b * Tn + q0 + 32 * w + row) * d + h * 64 + c * 8) = v;
+      }
     }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int id = it * 64 + lane, row = id >> 3, c = id & 7;
-    if (q0 + row < Tn) {
-      uint4 v = *(const uint4*)(ob + row * 144 + c * 16);
-      *(uint4*)(out + ((int64_t)b * Tn + q0 + row) * d + h * 64 + c * 8) = v;
+    if (w + 1 < QW) {   // the staging rows are rewritten by the next block: its reads above must have landed first
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
+thread_local int g_flash_qw = 2;   // option flash_qw: query blocks of 32 per wave in the encoder's flash attention (1 = the round-5 form)
 template <typename T16>
 void launch_enc_attn_flash_bf16(const T16* qkv, T16* out, int B, int T_, int H, hipStream_t s) {
-  dim3 grid((T_ + FA_QB - 1) / FA_QB, H, B);
-  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
+  if (g_flash_qw >= 2) {
+    dim3 grid((T_ + 255) / 256, H, B);
+    hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 2>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
+                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
+    return;
+  }
+  dim3 grid((T_ + 127) / 128, H, B);
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 1>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
                      (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
 }
 // q = [n_clips][n_q][d] (the n_q rows of a clip are consecutive), K / V = cross-KV cache of those clips, out like q
 template <typename T16>
 void launch_cross_attn_flash_bf16(const T16* q, const T16* K, const T16* V, T16* out, int n_clips, int n_q, int H, int Tk, hipStream_t s) {
-  dim3 grid((n_q + FA_QB - 1) / FA_QB, H, n_clips);
-  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, true>), grid, dim3(256), 32768, s, (const bf16_t*)q, (bf16_t*)out, n_q, H,
+  dim3 grid((n_q + 127) / 128, H, n_clips);   // prompt positions: at most 447 rows per clip - the 128-query form fills more workgroups
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, true, 1>), grid, dim3(256), 32768, s, (const bf16_t*)q, (bf16_t*)out, n_q, H,
                      (const bf16_t*)K, (const bf16_t*)V, Tk);
 }
 template void launch_enc_attn_flash_bf16<bf16_t>(const bf16_t*, bf16_t*, int, int, int, hipStream_t);
