@@ -8,6 +8,7 @@
 //   gemm_bf16_fast  128x128x64 tile, global_load_lds (16 B) double-buffered staging, XOR-swizzled LDS
 //                   image (swizzle applied on the SOURCE address, guide rule 21), XCD-aware tile order.
 #include "common.hpp"
+#include <type_traits>
 #include <mutex>
 #ifndef TTASR_V5_DMA
 #define TTASR_V5_DMA 0   // where the persistent GEMM issues stage t + 3 (lab builds: 1 / 2 / 3 = variants measured in round 5)
