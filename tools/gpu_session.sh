@@ -42,6 +42,11 @@ timeout 400 python bench.py --model large-v3-turbo --batch 32 --no-side --no-cpu
 timeout 400 python bench.py --model small --batch 8 --no-side --no-cpu-baseline > $O/bench_small_b8.json 2>/dev/null; echo "small rc=$?"
 timeout 400 python bench.py --new-tokens 444 --steps 3 --warmup 1 --no-side --no-cpu-baseline > $O/bench_444tok.json 2>/dev/null; echo "444 rc=$?"
 timeout 400 python bench.py --gpus 2 --steps 3 --warmup 1 --no-side --no-cpu-baseline > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$?"; head -c 300 $O/bench_gpus2_gloo.json; tail -2 $O/bench_gpus2.err
+# the launcher form that died inside RCCL in round 5 ("Duplicate GPU detected": two ranks, one device): must fall back to gloo by itself
+timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --no-side --no-cpu-baseline > $O/bench_gpus2_torchrun.json 2> $O/bench_gpus2_torchrun.err; echo "gpus2 under torch.distributed.run rc=$?"; tail -n 1 $O/bench_gpus2_torchrun.json | cut -c1-200; grep -m1 "ttasr.dist" $O/bench_gpus2_torchrun.err
+timeout 300 python tools/flash_ab.py > $O/flash_qw.jsonl 2>/dev/null; echo "flash_ab rc=$?"
+timeout 300 python tools/ragged_curve.py > $O/ragged_curve.jsonl 2>/dev/null; echo "ragged_curve rc=$?"
+timeout 300 python tools/beam_step_bench.py --clips 8 --beam 5 --new-tokens 16 > $O/beam_step.jsonl 2>/dev/null; echo "beam_step rc=$?"; cat $O/beam_step.jsonl | cut -c1-260
 timeout 400 python tools/gemm_ab.py --rounds 3 > $O/gemm_persistent.jsonl 2>/dev/null; echo "gemm_ab rc=$?"
 timeout 400 python tools/stream_bench.py --model large-v3 --streams 8 --rounds 6 --beam 5 --max-clips 8 > $O/streaming.jsonl 2>/dev/null; echo "stream rc=$?"; tail -1 $O/streaming.jsonl | cut -c1-300
 timeout 400 python tools/stream_bench.py --model large-v3 --streams 8 --rounds 6 --beam 5 --max-clips 8 --audio-ctx auto >> $O/streaming.jsonl 2>/dev/null; tail -1 $O/streaming.jsonl | cut -c1-300
