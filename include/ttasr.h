@@ -241,8 +241,7 @@ TTASR_API int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32
  * items at or below which the decode step's cross-attention workgroups keep 8 instead of 3 rows per lane in flight (0: never;
  * bit-identical); "xattn_mq_slices" [0 = automatic] frame slices of the shared-clip cross-attention (beam rows, prompt positions;
  * 1 ... 8, A/B); "flash_qw" [2] query blocks of 32 per wave in the encoder's MFMA flash attention (1: the round-5 form with 32
- * queries per wave; bit-identical); "flash_nb" [1] key tiles per workgroup barrier of that kernel (2: four LDS images, the waves meet
- * once per pair of tiles; bit-identical);
+ * queries per wave; bit-identical);
  * "enc_kernel_timing" [0] per-launch events in ttasr_encode (see ttasr_encoder_kernel_ms); "xkv_fp8" [0] (16-bit engines; opt-in serving
  * mode, NOT the measured configuration) keeps an OCP e4m3 copy of the cross-KV cache with one scale per (layer, K | V, clip, head),
  * built by the next ttasr_encode and read by the decode step's cross-attention (half the bytes of the dominant kernel).

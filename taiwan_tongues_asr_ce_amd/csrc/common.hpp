@@ -382,8 +382,6 @@ extern thread_local char g_launch_fault[160];
 void launch_fault(const char* fmt, ...);
 extern thread_local int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs
 extern thread_local int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant
-extern thread_local int g_flash_nb;           // option flash_nb (kernels_flash.hip): key tiles per workgroup barrier, 1 | 2
-void flash_attn_init(int device);             // once per device (ttasr_create): dynamic-LDS opt-in of the 64 KB flash forms
 extern thread_local int g_flash_qw;           // option flash_qw (kernels_flash.hip): query blocks of 32 per wave, 1 | 2
 extern thread_local int g_xattn_mq_slices;    // option xattn_mq_slices (A/B)
 extern thread_local int g_xattn_deep_items;   // option xattn_deep_items (kernels_attn.hip cross_attn_pipe_kernel)

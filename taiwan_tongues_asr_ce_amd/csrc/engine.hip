@@ -16,7 +16,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
-  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw; g_flash_nb = c->flash_nb; }   // this context's kernel variants for everything f launches
+  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw; }   // this context's kernel variants for everything f launches
   g_launch_fault[0] = 0;
   try {
     const int rc = f();
@@ -105,7 +105,6 @@ static int create_impl(const ttasr_config* cfg, int device_id, ttasr_ctx* owner,
   p->cur = p->stream;
   gemm_vocab_init(device_id);
   gemm_tiles_init(device_id);
-  flash_attn_init(device_id);
   {  // weights (+ packed decoder copies) + encoder workspaces + cross-KV + self-KV pool, in elements of the compute type
     const size_t d = p->d, ffn = p->ffn, T = p->T, B = p->maxB;
     const size_t w = owner ? 0 : ((size_t)cfg->enc_layers * (4 * d * d + 2 * d * ffn) + (size_t)cfg->dec_layers * (8 * d * d + 2 * d * ffn) * 2 + 2 * (size_t)p->V * d);

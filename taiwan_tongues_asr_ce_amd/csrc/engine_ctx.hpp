@@ -118,7 +118,6 @@ struct ttasr_ctx {
   std::atomic<int> sharers{0};
   bool destroy_pending = false;
   int32_t* row_cap_dev = nullptr;   // [maxB] per-row token budgets (st.row_cap; ttasr_generate_capped), "no budget" = 0x7f7f7f7f
-  int flash_nb = 1;                 // option flash_nb: key tiles per workgroup barrier in the flash attention (2 = four LDS images)
   int flash_qw = 2;                 // option flash_qw: query blocks of 32 per wave in the encoder's flash attention (1 = the round-5 kernel)
   int xattn_mq_slices = 0;          // option xattn_mq_slices (A/B): 0 = automatic
   int xattn_deep_items = 512;       // option xattn_deep_items: see kernels_attn.hip cross_attn_pipe_kernel (0: never stream deep; 512 = 2 per CU: measured optimum, profiles/r6_xattn_deep_sweep.jsonl)

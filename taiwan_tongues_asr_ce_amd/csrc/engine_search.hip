@@ -90,13 +90,12 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
   }
   else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
   else if (key == "ragged_exit") c->ragged_exit = on;
-  else if (key == "flash_nb") { if (v < 1 || v > 2) return 1; c->flash_nb = v; }
   else if (key == "flash_qw") { if (v < 1 || v > 2) return 1; c->flash_qw = v; }
   else if (key == "xattn_mq_slices") { if (v < 0 || v > 8) return 1; c->xattn_mq_slices = v; }
   else if (key == "xattn_deep_items") { if (v < 0 || v > 1 << 20) return 1; c->xattn_deep_items = v; }
   else return 1;
   g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0;
-  g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw; g_flash_nb = c->flash_nb;
+  g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw;
   drop_graphs(c);
   return 0;
 }

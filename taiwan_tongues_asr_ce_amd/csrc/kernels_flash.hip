@@ -14,7 +14,6 @@
 //   LDS swizzles: K chunk c of row k at c ^ ((k>>1)&7); V 64-byte half hf of row k at hf ^ ((k>>1)&1).
 #include "common.hpp"
 #include <type_traits>
-#include <mutex>
 
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -40,9 +39,7 @@ constexpr int FA_KB = 64;   // keys per tile; a workgroup = 4 waves x QW blocks 
 // kernel sat at 0.33 of the MFMA peak with 35 % of its wave cycles stalled (profiles/r5_flash_pmc.txt).  With TWO blocks a wave
 // feeds every K / V fragment it reads to two MFMAs (LDS bytes per flop halve), and the softmax VALU work of one block runs while the
 // other block's MFMAs are in flight: independent chains INSIDE a wave instead of three waves per SIMD arbitrating for the pipe.
-// NB = key tiles per workgroup barrier (round 6): 1 = two LDS images, a barrier after every tile (rounds 1-5); 2 = four images
-// (64 KB), the NEXT PAIR of tiles is requested while the current pair is computed and the four waves meet once per pair.
-template <typename T16, bool CROSS, int QW, int NB>
+template <typename T16, bool CROSS, int QW>
 __global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
                                                              int H, const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx,
                                                              int n_k_cross) {
@@ -165,11 +162,11 @@ __global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(co
   const int vq = (lane & 15) >> 2, vp4 = lane & 3, vg = (lane >> 4) & 1;
 
   // cur_tag: which LDS image this tile reads (compile-time: every LDS address is base + immediate); last_tag: the peeled last tile
-  // `last`: std::true_type / std::false_type (the peeled last tile of the NB = 1 loop: the masking code exists only there) or a
-  // runtime bool (NB = 2: a wave-uniform branch)
-  auto compute = [&](const int kt, auto cur_tag, auto last) {
-    const bool LAST = last;
+  auto tile = [&](const int kt, auto cur_tag, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
     constexpr int cur = decltype(cur_tag)::value;
+    // tile kt + 1 into the other image: its last readers (tile kt - 1) are behind the barrier every wave has passed
+    if (!LAST) FA_DMA(kt + 1, cur ^ 1);
     const char* Kb = smem + cur * 16384;
     const char* Vb = Kb + 8192;
     if (live) {
@@ -261,48 +258,21 @@ __global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(co
       }
     }
     }  // live
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 landed (explicit: see above)
+    __syncthreads();   // barrier: everybody's did
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  using B2 = std::integral_constant<int, 2>;
-  using B3 = std::integral_constant<int, 3>;
-  if constexpr (NB == 1) {
-    auto tile = [&](const int kt, auto cur_tag, auto last_tag) {
-      constexpr bool LAST = decltype(last_tag)::value;
-      constexpr int cur = decltype(cur_tag)::value;
-      // tile kt + 1 into the other image: its last readers (tile kt - 1) are behind the barrier every wave has passed
-      if (!LAST) FA_DMA(kt + 1, cur ^ 1);
-      compute(kt, cur_tag, last_tag);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt + 1 landed (explicit: see above)
-      __syncthreads();   // barrier: everybody's did
-    };
-    int kt = 0;
-    for (; kt + 2 < n_tiles; kt += 2) {
-      tile(kt, B0{}, std::false_type{});
-      tile(kt + 1, B1{}, std::false_type{});
-    }
-    if (kt + 2 == n_tiles) {
-      tile(kt, B0{}, std::false_type{});
-      tile(kt + 1, B1{}, std::true_type{});
-    } else {
-      tile(kt, B0{}, std::true_type{});
-    }
+  int kt = 0;
+  for (; kt + 2 < n_tiles; kt += 2) {
+    tile(kt, B0{}, std::false_type{});
+    tile(kt + 1, B1{}, std::false_type{});
+  }
+  if (kt + 2 == n_tiles) {
+    tile(kt, B0{}, std::false_type{});
+    tile(kt + 1, B1{}, std::true_type{});
   } else {
-    // pairs of tiles: pair p = tiles 2p, 2p + 1 in images (0, 1) for even p, (2, 3) for odd p.  The next pair's K / V are
-    // requested before this pair is computed (their images were last read two barriers ago), and the waves meet once per pair.
-    if (n_tiles > 1) { FA_DMA(1, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-    auto pair = [&](const int kt, auto ia, auto ib, auto na, auto nb) {
-      if (kt + 2 < n_tiles) FA_DMA(kt + 2, decltype(na)::value);
-      if (kt + 3 < n_tiles) FA_DMA(kt + 3, decltype(nb)::value);
-      compute(kt, ia, kt == n_tiles - 1);
-      if (kt + 1 < n_tiles) compute(kt + 1, ib, kt + 1 == n_tiles - 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    };
-    for (int kt = 0; kt < n_tiles; kt += 4) {
-      pair(kt, B0{}, B1{}, B2{}, B3{});
-      if (kt + 2 < n_tiles) pair(kt + 2, B2{}, B3{}, B0{}, B1{});
-    }
+    tile(kt, B0{}, std::true_type{});
   }
 
   // ---- epilogue: O^T[d][q] / l  ->  out[q][h*64 + d], transposed through LDS so rows leave as 128 B (one block at a time) ----
@@ -339,35 +309,23 @@ __global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(co
 }
 
 thread_local int g_flash_qw = 2;   // option flash_qw: query blocks of 32 per wave in the encoder's flash attention (1 = the round-5 form)
-thread_local int g_flash_nb = 1;   // option flash_nb: key tiles per workgroup barrier (2 = four LDS images, 64 KB)
-static std::once_flag g_flash_once[64];
-void flash_attn_init(int device) {   // once per device, from ttasr_create: the 64 KB forms need the dynamic-LDS opt-in
-  std::call_once(g_flash_once[device & 63], []() {
-    hipFuncSetAttribute((const void*)enc_attn_flash_kernel<bf16_t, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    hipFuncSetAttribute((const void*)enc_attn_flash_kernel<f16_t, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  });
-}
 template <typename T16>
 void launch_enc_attn_flash_bf16(const T16* qkv, T16* out, int B, int T_, int H, hipStream_t s) {
   if (g_flash_qw >= 2) {
     dim3 grid((T_ + 255) / 256, H, B);
-    if (g_flash_nb >= 2)
-      hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 2, 2>), grid, dim3(256), 65536, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
-                         (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
-    else
-      hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 2, 1>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
-                         (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
+    hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 2>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
+                       (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
     return;
   }
   dim3 grid((T_ + 127) / 128, H, B);
-  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 1, 1>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, false, 1>), grid, dim3(256), 32768, s, (const bf16_t*)qkv, (bf16_t*)out, T_, H,
                      (const bf16_t*)nullptr, (const bf16_t*)nullptr, 0);
 }
 // q = [n_clips][n_q][d] (the n_q rows of a clip are consecutive), K / V = cross-KV cache of those clips, out like q
 template <typename T16>
 void launch_cross_attn_flash_bf16(const T16* q, const T16* K, const T16* V, T16* out, int n_clips, int n_q, int H, int Tk, hipStream_t s) {
   dim3 grid((n_q + 127) / 128, H, n_clips);   // prompt positions: at most 447 rows per clip - the 128-query form fills more workgroups
-  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, true, 1, 1>), grid, dim3(256), 32768, s, (const bf16_t*)q, (bf16_t*)out, n_q, H,
+  hipLaunchKernelGGL((enc_attn_flash_kernel<T16, true, 1>), grid, dim3(256), 32768, s, (const bf16_t*)q, (bf16_t*)out, n_q, H,
                      (const bf16_t*)K, (const bf16_t*)V, Tk);
 }
 template void launch_enc_attn_flash_bf16<bf16_t>(const bf16_t*, bf16_t*, int, int, int, hipStream_t);
