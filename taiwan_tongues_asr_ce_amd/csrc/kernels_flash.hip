@@ -34,11 +34,12 @@ constexpr int FA_KB = 64;   // keys per tile; a workgroup = 4 waves x QW blocks 
 // CROSS = true: the decoder's cross-attention for MANY query rows per clip (a prompt prefill pass): q = [clip][Tn][d] rows, K / V
 // from the cross-KV cache [clip][head][n_k][64] - the clip's frames are streamed once for all of its prompt positions.
 // QW = query blocks of 32 per WAVE (round 6).  With one block (rounds 1-5) every wave re-reads the whole 16 KB K / V tile from LDS
-// for its 32 queries: per wave and tile 16 KB of LDS reads stand against 16 MFMAs of 32 cycles - with four SIMDs sharing one LDS
-// port (128 B per cycle) the LDS reads of a round of four wave-tiles take as long as its MFMAs (512 cycles each), which is why the
-// kernel sat at 0.33 of the MFMA peak with 35 % of its wave cycles stalled (profiles/r5_flash_pmc.txt).  With TWO blocks a wave
-// feeds every K / V fragment it reads to two MFMAs (LDS bytes per flop halve), and the softmax VALU work of one block runs while the
-// other block's MFMAs are in flight: independent chains INSIDE a wave instead of three waves per SIMD arbitrating for the pipe.
+// for its 32 queries: 16 KB per wave and tile = 64 cycles of the LDS array at ds_read_b128's 256 B per cycle, so a round of four
+// wave-tiles (one per SIMD) keeps the one LDS port of the CU busy for 256 cycles against the 512 cycles its 16 MFMAs of 32 cycles
+// take on each SIMD - half the matrix time, before bank conflicts and the LDS-DMA landing of the next tile.  With TWO blocks a wave
+// feeds every K / V fragment it reads to two MFMAs (LDS bytes per flop halve), and it owns two independent softmax chains.
+// Measured: bit-identical, 13.87 -> 13.55 ms in situ (profiles/r6_flash_qw.jsonl) - a few per cent, because the kernel's first
+// limit is vector issue (two v_exp_f32 per MFMA at head_dim 64: DESIGN.md 4.11), not the LDS port.
 template <typename T16, bool CROSS, int QW>
 __global__ __launch_bounds__(256, QW == 2 ? 2 : 3) void enc_attn_flash_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int Tn,
                                                              int H, const bf16_t* __restrict__ kx, const bf16_t* __restrict__ vx,
