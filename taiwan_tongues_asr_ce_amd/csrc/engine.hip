@@ -39,6 +39,9 @@ const char* ttasr_version(void) { return "ttasr 0.4 (gfx950, HIP; f32 | bf16 | f
 const char* ttasr_last_error(const ttasr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 static int create_impl(const ttasr_config* cfg, int device_id, ttasr_ctx* owner, ttasr_ctx** out_ctx);
+// `sharers` / `destroy_pending` of every context change under this lock: an owner and its last sharer may be destroyed from two
+// threads at once, and exactly one of them must free the owner
+static std::mutex g_share_mu;
 
 int ttasr_create(const ttasr_config* cfg, int device_id, ttasr_ctx** out_ctx) {
   return guarded(nullptr, [&]() -> int { return create_impl(cfg, device_id, nullptr, out_ctx); });
@@ -50,7 +53,8 @@ int ttasr_create_shared(ttasr_ctx* owner, int32_t max_batch, ttasr_ctx** out_ctx
   *out_ctx = nullptr;
   if (owner->weight_owner) owner = owner->weight_owner;   // sharing with a sharer = sharing with its owner
   if (!owner->finalized) return fail(nullptr, TTASR_E_INVALID, "the owner's weights are not finalized (ttasr_finalize_weights first)");
-  if (owner->destroy_pending) return fail(nullptr, TTASR_E_INVALID, "the owner context was destroyed");
+  { std::lock_guard<std::mutex> lk(g_share_mu);
+    if (owner->destroy_pending) return fail(nullptr, TTASR_E_INVALID, "the owner context was destroyed"); }
   ttasr_config cfg = owner->cfg;
   if (max_batch > 0) cfg.max_batch = max_batch;
   return create_impl(&cfg, owner->device, owner, out_ctx);
@@ -66,6 +70,7 @@ static void adopt_weights(ttasr_ctx* c, ttasr_ctx* o) {
   c->dec_narrow = o->dec_narrow; c->weights_packed = o->weights_packed;
   c->finalized = true;
   c->weight_owner = o;
+  std::lock_guard<std::mutex> lk(g_share_mu);
   o->sharers.fetch_add(1);
 }
 
@@ -158,10 +163,11 @@ void ttasr_destroy(ttasr_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->sharers.load() > 0 && !c->destroy_pending) {   // other contexts still read these weights: the last of them frees this one
-    c->destroy_pending = true;
-    return;
-  }
+  { std::lock_guard<std::mutex> lk(g_share_mu);
+    if (c->sharers.load() > 0 && !c->destroy_pending) {   // other contexts still read these weights: the last of them frees this one
+      c->destroy_pending = true;
+      return;
+    } }
   ttasr_ctx* owner = c->weight_owner;
   drop_graphs(c);
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -171,7 +177,11 @@ void ttasr_destroy(ttasr_ctx* c) {
   if (c->pinned_beam) hipHostFree(c->pinned_beam);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
-  if (owner && owner->sharers.fetch_sub(1) == 1 && owner->destroy_pending) ttasr_destroy(owner);   // we were the last sharer
+  if (owner) {
+    bool last;
+    { std::lock_guard<std::mutex> lk(g_share_mu); last = owner->sharers.fetch_sub(1) == 1 && owner->destroy_pending; }
+    if (last) ttasr_destroy(owner);   // we were the last sharer of an owner that is already gone for its user
+  }
 }
 
 
@@ -747,12 +757,12 @@ int ttasr_bench_kernel(ttasr_ctx* c, const char* name, int32_t B, int32_t iters,
     } else if (k == "dec_gemm_fc1") {
       GemmArgs g; g.A = c->dh; g.W = c->dec[0].w1; g.M = B; g.N = c->ffn; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ffn; g.epi.bias = c->dec[0].b1; g.epi.act = 1; g.epi.out_t = c->dmid;
-      TT_DISPATCH(c, sched_dec_gemm(c, g, c->lowp ? c->dec[0].w1_sh : nullptr));
+      sched_dec_gemm(c, g, c->lowp ? c->dec[0].w1_sh : nullptr);
       bytes = (ffn * d + (double)B * (d + ffn)) * e; flops = 2.0 * B * d * ffn;
     } else if (k == "logits_gemm") {
       GemmArgs g; g.A = c->dh; g.W = c->emb; g.M = B; g.N = c->V; g.K = c->d; g.lda = c->d; g.ldw = c->d;
       g.epi.ldc = c->ldv; g.epi.out_f32 = c->logits;
-      TT_DISPATCH(c, sched_dec_gemm(c, g, c->lowp ? c->emb_sh : nullptr));
+      sched_dec_gemm(c, g, c->lowp ? c->emb_sh : nullptr);
       bytes = (double)c->V * d * e + (double)B * c->V * 4.0; flops = 2.0 * B * d * c->V;
     } else {
       return fail(c, TTASR_E_INVALID, "unknown kernel '%s'", name);

@@ -137,3 +137,30 @@ def test_pipelined_folder_path_equals_the_serial_one_file_by_file():
         m.transcribe_groups([files[0:2], [np.zeros((2, 2), np.float32)]], **kw)
     assert _flat(m.transcribe_groups(groups[:2], **kw)) == _flat(serial[:2])
     m.close()
+
+
+def test_owner_and_last_sharer_destroyed_from_two_threads_at_once():
+    """`sharers` / `destroy_pending` change under one lock: whichever of the two destroys comes second frees the owner - never
+    neither (a leaked context holds >= 64 MiB of arena), never both."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    dims = PRESETS["micro"]
+    sd = synth.state_dict(dims)
+    warm = Engine(dims, COMPUTE_BF16, 2)
+    warm.load_weights(sd.items())
+    warm.close()
+    f0 = _free()
+    for _ in range(24):
+        owner = Engine(dims, COMPUTE_BF16, 2)
+        owner.load_weights(sd.items())
+        twin = Engine(dims, COMPUTE_BF16, 2, share_weights_with=owner)
+        gate = threading.Barrier(2)
+
+        def end(e):
+            gate.wait()
+            e.close()
+        th = [threading.Thread(target=end, args=(e,)) for e in (owner, twin)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    assert _free() >= f0 - (512 << 20), (f0, _free())                   # 24 leaked owners would hold >= 1.5 GB
