@@ -4,6 +4,9 @@ attention class of a real encoder pass, the encoder phase, and whether the two f
 import json, sys
 sys.path.insert(0, '.')
 import numpy as np
+from taiwan_tongues_asr_ce_amd import _lib
+if len(sys.argv) > 3:
+    _lib.LIB_PATH = sys.argv[3]          # a variant build of the library
 from taiwan_tongues_asr_ce_amd import synth
 from taiwan_tongues_asr_ce_amd.config import COMPUTE_BF16, COMPUTE_F16, PRESETS
 from taiwan_tongues_asr_ce_amd.engine import Engine
