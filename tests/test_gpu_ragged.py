@@ -187,3 +187,34 @@ def test_beam_search_with_clips_that_finish_early_is_unchanged(world):
     off = e.generate_beam([prompt] * 8, 5, opts)
     assert on.tokens == off.tokens and np.array_equal(on.sum_logprob, off.sum_logprob)
     e.close()
+
+
+@pytest.mark.parametrize("n", [48, 72], ids=["48-rows-remapped", "72-rows-own-flag"])
+def test_wide_batches_leave_finished_rows_out(world, n):
+    """Batches of 33 ... 64 rows keep the live-row remap (lane i of every wave holds done[i]: the ballot covers up to 64 rows);
+    wider ones test their own row's flag only.  Both: a capped row equals the uncapped row cut at its budget, the static batch
+    gives the same bits, and budgets that empty the FRONT of the batch (every workgroup of the remapped form then serves a row
+    far from its slot) change nothing for the rows that stay."""
+    sd, _, _ = world
+    clips = _clips(n)
+    e = _engine(COMPUTE_BF16, sd, max_batch=n)
+    st = e.special
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    opts = e.gen_opts(20, False, suppress_eot=True, check_interval=1 << 20)
+    e.log_mel(clips, want_output=False)
+    e.encode(n)
+    full = e.generate([prompt] * n, opts)
+    caps = _caps(seed=n, lo=1, hi=20, n=n)
+    cut = e.generate([prompt] * n, opts, row_max_new=caps)
+    e.set_option("ragged_exit", 0)
+    static = e.generate([prompt] * n, opts, row_max_new=caps)
+    e.set_option("ragged_exit", 1)
+    assert static.tokens == cut.tokens and np.array_equal(static.sum_logprob, cut.sum_logprob)
+    for r in range(n):
+        assert cut.tokens[r] == full.tokens[r][:caps[r]], (n, r, int(caps[r]))
+    front = np.full(n, 1, np.int32)
+    front[n // 2:] = 20                                      # the first half leaves after one token
+    tail = e.generate([prompt] * n, opts, row_max_new=front)
+    for r in range(n // 2, n):
+        assert tail.tokens[r] == full.tokens[r] and tail.sum_logprob[r] == full.sum_logprob[r], (n, r)
+    e.close()
