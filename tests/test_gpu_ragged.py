@@ -218,3 +218,30 @@ def test_wide_batches_leave_finished_rows_out(world, n):
     for r in range(n // 2, n):
         assert tail.tokens[r] == full.tokens[r] and tail.sum_logprob[r] == full.sum_logprob[r], (n, r)
     e.close()
+
+
+def test_sampled_rows_of_a_clip_that_finish_at_different_steps(world):
+    """Temperature sampling: the best_of rows of a clip share its cross-KV stream (cross_attn_mq_kernel) and end at DIFFERENT steps
+    once EOT is likely - a partly finished group is computed whole and only its live rows are merged, a fully finished group
+    streams nothing.  All but a dozen text tokens are suppressed, so that EOT carries about 1 / 13 of the mass at temperature 4:
+    the clips' best rows must be the same rows, token for token and bit for bit in their scores, with the early exit off."""
+    sd, clips, _ = world
+    e = _engine(COMPUTE_BF16, sd, max_batch=40)
+    st = e.special
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    keep = set(range(300, 312)) | {st.eot}
+    sup = [t for t in range(DIMS.vocab) if t not in keep]
+    e.log_mel(clips[:8], want_output=False)
+    e.encode(8)
+    opts = e.gen_opts(24, False, suppress=sup, begin_suppress=[], no_speech=False, check_interval=4)
+    seen_short = 0
+    for seed in (1, 2, 3):
+        on = e.generate_sample([prompt] * 8, 5, opts, temperature=4.0, seed=seed)
+        e.set_option("ragged_exit", 0)
+        off = e.generate_sample([prompt] * 8, 5, opts, temperature=4.0, seed=seed)
+        e.set_option("ragged_exit", 1)
+        assert on.tokens == off.tokens and np.array_equal(on.sum_logprob, off.sum_logprob), seed
+        assert all(set(t) <= keep for t in on.tokens)
+        seen_short += sum(len(t) < 24 for t in on.tokens)
+    assert seen_short >= 4, seen_short                       # rows did end early (and at different lengths) in these runs
+    e.close()
