@@ -125,6 +125,9 @@ def decode_audio(path: str, sampling_rate: int = SAMPLE_RATE) -> np.ndarray:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif width == 4:
         x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 3:   # 24-bit PCM, little endian: sign-extend through the top byte of an int32
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        x = ((b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)) << 8 >> 8).astype(np.float32) / 8388608.0
     elif width == 1:
         x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
     else:

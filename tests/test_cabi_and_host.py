@@ -155,6 +155,33 @@ def test_decode_audio_wav(tmp_path):
     assert abs(int(np.argmax(np.abs(f))) - 440) <= 1
 
 
+def test_decode_audio_wav_sample_widths(tmp_path):
+    """8- / 16- / 24- / 32-bit PCM carry the same signal (24-bit studio files are common in the field; asr_core.py:118 globs *.wav)."""
+    import wave
+    from taiwan_tongues_asr_ce_amd.model import decode_audio
+    sig = 0.6 * np.sin(2 * np.pi * 200 * np.arange(16000) / 16000) - 0.2
+    ref = None
+    for width in (2, 3, 4, 1):
+        q = np.round(sig * (2 ** (8 * width - 1) - 1)).astype(np.int64)
+        if width == 1:
+            raw = (q + 128).astype(np.uint8).tobytes()
+        elif width == 3:
+            u = (q & 0xFFFFFF).astype(np.uint32)
+            raw = np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=1).astype(np.uint8).tobytes()
+        else:
+            raw = q.astype("<i%d" % width).tobytes()
+        p = str(tmp_path / f"w{width}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(width); w.setframerate(16000)
+            w.writeframes(raw)
+        x = decode_audio(p)
+        assert x.dtype == np.float32 and len(x) == 16000
+        np.testing.assert_allclose(x, sig, atol=2.0 ** -(8 * width - 2) + 1e-6)
+        if ref is None:
+            ref = x
+        assert x.min() < -0.79 and x.max() > 0.39                                   # the negative half survived the sign extension
+
+
 def test_synth_weights_are_order_independent():
     from taiwan_tongues_asr_ce_amd import synth
     d = PRESETS["micro"]
