@@ -118,10 +118,18 @@ def decode_audio(path: str, sampling_rate: int = SAMPLE_RATE) -> np.ndarray:
             return (np.concatenate(chunks).astype(np.float32) / 32768.0) if chunks else np.zeros(0, np.float32)
         except ImportError:
             raise RuntimeError(f"{path}: no decoder for this container (install soundfile, librosa or av); RIFF/WAV needs none")
-    with wave.open(path, "rb") as w:
-        n_ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
-        raw = w.readframes(n)
-    if width == 2:
+    is_float = False
+    try:
+        with wave.open(path, "rb") as w:
+            n_ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+            raw = w.readframes(n)
+    except wave.Error:
+        # the stdlib reader only takes format tag 1; IEEE-float files (tag 3: Audacity / DAW exports) and WAVE_FORMAT_EXTENSIBLE
+        # (tag 0xFFFE: multichannel / > 16-bit writers) are plain RIFF all the same
+        n_ch, width, sr, raw, is_float = _read_riff_wave(path)
+    if is_float:
+        x = np.frombuffer(raw, dtype="<f4" if width == 4 else "<f8").astype(np.float32)
+    elif width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif width == 4:
         x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
@@ -140,6 +148,38 @@ def decode_audio(path: str, sampling_rate: int = SAMPLE_RATE) -> np.ndarray:
         g = gcd(sr, sampling_rate)
         x = resample_poly(x, sampling_rate // g, sr // g).astype(np.float32)
     return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def _read_riff_wave(path: str):
+    """(channels, bytes per sample, rate, data bytes, is_float) of a RIFF/WAVE file whose `fmt ` chunk says PCM (1), IEEE float
+    (3) or EXTENSIBLE (0xFFFE, sub-format PCM / float)."""
+    import struct
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        cid, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
+        body = blob[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            data = body            # (a streamed file's size field of 0 / 0xFFFFFFFF: the slice is whatever is there)
+            if size in (0, 0xFFFFFFFF):
+                data = blob[pos + 8:]
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None or len(fmt) < 16:
+        raise ValueError(f"{path}: RIFF/WAVE without fmt / data chunk")
+    tag, n_ch, sr, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:
+        tag = struct.unpack("<H", fmt[24:26])[0]          # first two bytes of the sub-format GUID
+    if tag not in (1, 3) or n_ch < 1 or bits % 8 or (tag == 3 and bits not in (32, 64)):
+        raise ValueError(f"{path}: unsupported WAVE format tag {tag}, {bits} bits")
+    width = bits // 8
+    data = data[:len(data) - len(data) % (width * n_ch)]
+    return n_ch, width, sr, data, tag == 3
 
 
 def _read_hf_dir(path: str) -> Tuple[WhisperDims, Iterable[Tuple[str, np.ndarray]]]:

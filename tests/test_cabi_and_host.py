@@ -182,6 +182,37 @@ def test_decode_audio_wav_sample_widths(tmp_path):
         assert x.min() < -0.79 and x.max() > 0.39                                   # the negative half survived the sign extension
 
 
+def test_decode_audio_float_and_extensible_wav(tmp_path):
+    """IEEE-float (tag 3) and WAVE_FORMAT_EXTENSIBLE (tag 0xFFFE) files - what DAWs and multichannel writers emit, and what the
+    stdlib `wave` reader of this Python refuses - decode to the same samples as their 16-bit twin."""
+    import struct
+    from taiwan_tongues_asr_ce_amd.model import decode_audio
+    sig = (0.5 * np.sin(2 * np.pi * 300 * np.arange(8000) / 8000)).astype(np.float32)           # 8 kHz: also resampled
+    st = np.stack([sig, sig], axis=1)
+
+    def riff(fmt, data, junk=b""):
+        chunks = junk + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data
+        return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+    f32 = riff(struct.pack("<HHIIHH", 3, 2, 8000, 8000 * 8, 8, 32), st.astype("<f4").tobytes(),
+               junk=b"LIST" + struct.pack("<I", 5) + b"abcde\0")                                  # an odd-sized chunk before fmt
+    guid_pcm = struct.pack("<H", 1) + bytes.fromhex("000000001000800000aa00389b71")
+    ext = riff(struct.pack("<HHIIHHHHI", 0xFFFE, 2, 8000, 8000 * 4, 4, 16, 22, 16, 3) + guid_pcm,
+               np.round(st * 32767).astype("<i2").tobytes())
+    outs = []
+    for name, blob in (("f32.wav", f32), ("ext.wav", ext)):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        x = decode_audio(str(p))
+        assert x.dtype == np.float32 and abs(len(x) - 16000) <= 1
+        outs.append(x)
+    np.testing.assert_allclose(outs[0], outs[1], atol=2e-4)
+    f = np.abs(np.fft.rfft(outs[0][:16000] * np.hanning(16000)))
+    assert abs(int(np.argmax(f)) - 300) <= 1
+    (tmp_path / "bad.wav").write_bytes(b"RIFFxxxxWAVEjunk")
+    with pytest.raises(ValueError):
+        decode_audio(str(tmp_path / "bad.wav"))
+
+
 def test_synth_weights_are_order_independent():
     from taiwan_tongues_asr_ce_amd import synth
     d = PRESETS["micro"]
