@@ -804,10 +804,11 @@ def main():
                 e3.close()
                 engines.remove(e3)
             if not args.no_side and args.compute == "bf16" and not args.xkv_fp8 and args.model == "large-v3":
-                # folder: the reference's folder tool (asr_core.py:151: one file at a time) on 12 synthetic recordings of 60 s, beam 5,
-                # <= 64 tokens per 30-s window, through WhisperModel - groups of 6 files in lock step, ONE group at a time
-                # (pipeline_depth 1) against TWO groups in flight on two engine contexts that share one copy of the weights
-                # (pipeline_depth 2: round 6).  Same groups -> identical results; audio-s/s = 720 s of audio / wall time.
+                # folder: the reference's folder tool (asr_core.py:151: one file at a time) on 48 synthetic recordings of 60 s, beam 5,
+                # <= 64 tokens per 30-s window, through WhisperModel - groups of 24 files in lock step (120 decode rows: what the
+                # folder tool's default context carries), ONE group at a time (pipeline_depth 1) against TWO groups in flight on two
+                # engine contexts that share one copy of the weights (pipeline_depth 2: round 6).  Same groups -> identical results;
+                # audio-s/s = 2 880 s of audio / wall time.  (12 files in groups of 6 - 30 rows - measured 595 -> 892: profiles/.)
                 for e_ in list(engines):          # the model below builds its own contexts: release the bench engine's 20 GB first
                     e_.close()
                 engines.clear()
@@ -815,10 +816,10 @@ def main():
                 from taiwan_tongues_asr_ce_amd.model import WhisperModel
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    wm = WhisperModel(f"synthetic:{args.model}", device="cuda", device_index=local, compute_type="bfloat16", max_batch=30,
+                    wm = WhisperModel(f"synthetic:{args.model}", device="cuda", device_index=local, compute_type="bfloat16", max_batch=120,
                                       pipeline_depth=2)
-                    files = [np.concatenate([synth.tonal_clip(2 * i), synth.noise_clip(2 * i + 1)]) for i in range(12)]
-                    groups = [files[:6], files[6:]]
+                    files = [np.concatenate([synth.tonal_clip(2 * i), synth.noise_clip(2 * i + 1)]) for i in range(48)]
+                    groups = [files[:24], files[24:]]
                     kwf = dict(language="zh", beam_size=5, temperature=0.0, log_prob_threshold=None, max_new_tokens=64)
                     wm.transcribe_groups(groups, pipeline_depth=2, **kwf)             # warm-up: both lanes, graphs
                     res, wall = {}, {}
@@ -828,8 +829,8 @@ def main():
                         wall[depth] = min(wall.get(depth, 1e9), time.perf_counter() - ts_)
                         res[depth] = [[(sg.start, sg.end, tuple(sg.tokens)) for sg in segs] for g_ in r_ for segs, _ in g_]
                     side["folder"] = {
-                        "workload": "12 x 60 s synthetic recordings, beam 5, <= 64 tokens per window, 6 files in lock step per group",
-                        "serial_audio_s_per_s": round(720.0 / wall[1], 1), "pipelined_audio_s_per_s": round(720.0 / wall[2], 1),
+                        "workload": "48 x 60 s synthetic recordings, beam 5, <= 64 tokens per window, 24 files (120 decode rows) in lock step per group",
+                        "serial_audio_s_per_s": round(2880.0 / wall[1], 1), "pipelined_audio_s_per_s": round(2880.0 / wall[2], 1),
                         "serial_s": round(wall[1], 3), "pipelined_s": round(wall[2], 3), "speed_up": round(wall[1] / wall[2], 3),
                         "results_identical": res[1] == res[2], "engine_contexts": len(wm._lanes),
                         "second_context_shares_weights": bool(wm._lanes[1].shares_weights),

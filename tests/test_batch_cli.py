@@ -157,3 +157,24 @@ def test_pipelined_folder_keeps_the_groups_and_the_results(tmp_path, monkeypatch
     logs = []
     res = batch_cli.process_audio_folder(str(folder), model=broken, log=logs.append)
     assert res["detailed_results"] == want["detailed_results"] and any("pipelined transcription failed" in str(m) for m in logs)
+
+
+def test_few_files_are_split_over_the_contexts(tmp_path, monkeypatch):
+    """Fewer files than one full group per context (the default context carries 24 files): one group per context instead of one
+    big group beside an idle lane; --group-files keeps whatever the caller asked for."""
+    monkeypatch.chdir(tmp_path)
+    folder = tmp_path / "audio"; folder.mkdir()
+    for i in range(5):
+        _wav(folder / f"f{i}.wav", 100 * (i + 1))
+
+    class Wide(_PipelinedModel):
+        max_batch = 120                                                          # 24 files per engine pass
+    m = Wide([])
+    batch_cli.process_audio_folder(str(folder), model=m, log=lambda *_: None)
+    assert m.pipelined == [(2, [[100, 200, 300], [400, 500]])]
+    m1 = Wide([])
+    batch_cli.process_audio_folder(str(folder), model=m1, log=lambda *_: None, pipeline_depth=1)
+    assert m1.groups == [[100, 200, 300, 400, 500]] and m1.pipelined == []
+    m2 = Wide([])
+    batch_cli.process_audio_folder(str(folder), model=m2, log=lambda *_: None, group_files=4)
+    assert m2.groups == [[100, 200, 300, 400], [500]]
