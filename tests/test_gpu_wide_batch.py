@@ -69,3 +69,56 @@ def test_rows_beyond_32_decode_like_the_first_32():
         if agree[a]:
             assert abs(float(wide.sum_logprob[a]) - float(narrow.sum_logprob[a % 6])) < 0.05 * max(1, len(wide.tokens[a])), a
     e.close()
+
+
+def test_measured_width_at_120_rows():
+    """The same at large-v3 WIDTH (d 1280, 20 heads, ffn 5120: the K splits, block heights and the looped fc1 form that the folder
+    tool's 120-row contexts actually launch), two layers each: rows of the fourth row group graded by the oracle under teacher
+    forcing, and the 24-clip beam search against the same clips searched six at a time."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine, default_suppress
+    from oracle_checks import encode_chunked
+    pd = PRESETS["large-v3-w2"]
+    dims = R.Dims(**pd.as_dict())
+    sd = synth.state_dict(pd)
+    e = Engine(pd, COMPUTE_BF16, 120)
+    e.load_weights(sd.items())
+    st = e.special
+    base = [synth.noise_clip(0), synth.tonal_clip(1), synth.burst_clip(2), synth.noise_clip(3), synth.tonal_clip(4), synth.noise_clip(5)]
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    clips = [base[b % 6] for b in range(120)]
+    e.log_mel(clips, want_output=False)
+    e.encode(120)
+    opts = e.gen_opts(12, False, suppress_eot=True)
+    got = e.generate([prompt] * 120, opts).tokens
+    Wb = R.to_torch(sd, round_bf16=True)
+    rules = R.Rules(eot=st.eot, no_timestamps=st.no_timestamps, timestamp_begin=st.timestamp_begin,
+                    suppress=default_suppress(st, dims.vocab), begin_suppress=[220, st.eot], timestamps=False)
+    rules.suppress_eot = True
+    enc = encode_chunked(np.stack([R.log_mel(c, pd.n_mels) for c in base]), Wb, dims)
+    worst = 0.0
+    for b in (97, 103, 110, 119):                                      # fourth row group
+        toks = got[b]
+        xkv = R.cross_kv(enc[b % 6:b % 6 + 1], Wb, dims)
+        cache = R.SelfCache.empty(dims.dec_layers)
+        logits = None
+        for t in prompt:
+            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
+        for i, t in enumerate(toks):
+            s = R.apply_rules(logits[0], toks[:i], rules)
+            gap = float(s.max() - s[t])
+            worst = max(worst, gap)
+            assert s[t] > -np.inf and gap < 0.15, (b, i, gap)
+            logits = R.decoder_forward(torch.full((1, 1), t), cache, xkv, Wb, dims)[:, 0]
+    opts_b = e.gen_opts(12, False)
+    e.log_mel(clips[:24], want_output=False)
+    e.encode(24)
+    wide = e.generate_beam([prompt] * 24, 5, opts_b)
+    e.log_mel(base, want_output=False)
+    e.encode(6)
+    narrow = e.generate_beam([prompt] * 6, 5, opts_b)
+    agree = [wide.tokens[a] == narrow.tokens[a % 6] for a in range(24)]
+    assert np.mean(agree) >= 0.8, np.mean(agree)
+    for a in range(24):
+        if agree[a]:
+            assert abs(float(wide.sum_logprob[a]) - float(narrow.sum_logprob[a % 6])) < 0.05 * max(1, len(wide.tokens[a])), a
+    e.close()
