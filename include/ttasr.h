@@ -235,7 +235,7 @@ TTASR_API int ttasr_dtw(const float* cost, int32_t n_rows, int32_t n_cols, int32
  * steps between two host polls replay as one graph; "generic_kernels" [0] the 64x64 generic
  * GEMM / per-row kernels everywhere; "prefill_tiled" [0]; "prefill_ns_min" [2] (tokens); "enc_residual_epilogue" [0];
  * "enc_gemm" [0] = 1 | 2 | 3 | 4 forces one encoder GEMM kernel; "enc_gemm_persistent" [1] persistent 256x256 GEMM workgroups (bit-identical to the one-tile-per-workgroup form); "dec_narrow_blocks" [1] 20-row n-blocks in the packed decode matrix whose 20-row block count is a multiple of the 256 CUs (large-v3 family: fc1 = 256 workgroups instead of 160; a weight LAYOUT choice: set it before the first ttasr_load_tensor, later changes are refused); "enc_ln_defer" [1] one f32 read-modify-write of the encoder's residual stream per layer instead of two (bit-identical); "enc_gemm_tail" [1] the persistent GEMM's last partial round of workgroups re-tiled with 192- / 128-row tiles where the plan beats the plain tiling (bit-identical); "xkv_grouped" [1] the cross-KV projections of all decoder layers as ONE grouped launch of that kernel (bit-identical to one launch per layer); "ksplit_out" / "ksplit_q" / "ksplit_qkv" / "ksplit_fc2" [0 =
- * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "xattn_pipeline" [1] (software-pipelined cross-attention), "weights_nontemporal" [1] (all per context
+ * automatic] K slices of the decode GEMMs; "xattn_nontemporal" [1], "xattn_pipeline" [1] (software-pipelined cross-attention), "weights_nontemporal" [1], "dec_x_lds" [1] (the decode GEMMs stage their activation tile through LDS with coalesced loads; 0 = fragment loads straight from memory, bit-identical) (all per context
  * since round 4); "ragged_exit" [1] finished rows of a decode batch leave its attention kernels (0: static batch, every row
  * streams its cross-KV until the last one ends; live rows are bit-identical either way); "xattn_deep_items" [512] live (row, head)
  * items at or below which the decode step's cross-attention workgroups keep 8 instead of 3 rows per lane in flight (0: never;

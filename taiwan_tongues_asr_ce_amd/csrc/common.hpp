@@ -380,6 +380,7 @@ template <> inline const char* sig_type<struct f16_t>() { return "f16_t"; }
 // call that was running returns TTASR_E_INVALID with this text (engine.hip guarded()).  A library never abort()s its host.
 extern thread_local char g_launch_fault[160];
 void launch_fault(const char* fmt, ...);
+extern thread_local int g_skinny_x_lds;  // option dec_x_lds: decode GEMMs stage their activation tile through LDS (kernels_skinny.hip)
 extern thread_local int g_skinny_nt;     // option weights_nontemporal: nontemporal weight loads in the decode GEMMs
 extern thread_local int g_xattn_variant;  // option xattn_nontemporal: cross-attention kernel variant
 extern thread_local int g_flash_qw;           // option flash_qw (kernels_flash.hip): query blocks of 32 per wave, 1 | 2

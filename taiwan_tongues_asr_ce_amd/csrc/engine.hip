@@ -16,7 +16,7 @@ static int guarded(ttasr_ctx* c, F&& f) {
     ~Busy() { if (c && own) c->busy.clear(std::memory_order_release); }
   } busy(c);
   if (!busy.own) return TTASR_E_INVALID;
-  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw; }   // this context's kernel variants for everything f launches
+  if (c) { g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0; g_skinny_x_lds = c->dec_x_lds ? 1 : 0; g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw; }   // this context's kernel variants for everything f launches
   g_launch_fault[0] = 0;
   try {
     const int rc = f();

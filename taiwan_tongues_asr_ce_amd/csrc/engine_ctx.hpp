@@ -140,6 +140,7 @@ struct ttasr_ctx {
   bool dec_narrow = true;   // option dec_narrow_blocks: 20-row n-blocks for the decode matrices whose 32-row block count does not fill the 256 CUs evenly (fixed once weights are packed)
   bool weights_packed = false;
   bool enc_ln_defer = true; // option enc_ln_defer = 0: every encoder LayerNorm folds its delta into the f32 residual stream (two read-modify-writes per layer; A/B testing, bit-identical)
+  bool dec_x_lds = true;    // option dec_x_lds = 0: decode GEMM activation fragments loaded straight from memory (the round-5 form; A/B, bit-identical)
   bool gemm_tail = true;    // option enc_gemm_tail = 0: plain 256-row tiling in the persistent encoder GEMM (A/B testing; bit-identical)
   bool xkv_grouped = true;  // option xkv_grouped = 0: one cross-KV GEMM launch per decoder layer instead of one grouped launch (A/B testing; bit-identical)
   bool multi_step = true;   // option multi_step_graph = 0: one graph replay per decode step (A/B testing)

@@ -89,12 +89,14 @@ int set_option(ttasr_ctx* c, const std::string& key, int v) {
     c->xkv_fp8 = on; c->xkv8_valid = false;   // the e4m3 copy is (re)built by the next encode
   }
   else if (key == "weights_nontemporal") c->weights_nt = on ? 1 : 0;
+  else if (key == "dec_x_lds") c->dec_x_lds = on;
   else if (key == "ragged_exit") c->ragged_exit = on;
   else if (key == "flash_qw") { if (v < 1 || v > 2) return 1; c->flash_qw = v; }
   else if (key == "xattn_mq_slices") { if (v < 0 || v > 8) return 1; c->xattn_mq_slices = v; }
   else if (key == "xattn_deep_items") { if (v < 0 || v > 1 << 20) return 1; c->xattn_deep_items = v; }
   else return 1;
   g_xattn_variant = c->xattn_nt | (c->xattn_pipe << 1); g_skinny_nt = c->weights_nt; g_skinny_narrow = c->dec_narrow ? 1 : 0;
+  g_skinny_x_lds = c->dec_x_lds ? 1 : 0;
   g_xattn_deep_items = c->xattn_deep_items; g_xattn_mq_slices = c->xattn_mq_slices; g_flash_qw = c->flash_qw;
   drop_graphs(c);
   return 0;

@@ -82,6 +82,22 @@ template void launch_shuffle_cast<f16_t>(const float*, f16_t*, int, int, int, hi
 // NW waves per workgroup, each owning steps_per_wave k-steps of 16; RB groups of 32 batch rows share every weight
 // fragment (RB = 1 is the B <= 32 kernel of the benchmark; RB = 2..4 carry 64..128 rows through one weight stream,
 // which is what amortises the per-step latency when more clips are in flight).
+thread_local int g_skinny_x_lds = 1;   // option dec_x_lds: the decode GEMMs stage their activation tile through LDS (0 = fragment loads straight from memory; bit-identical)
+// dynamic LDS of gemm_skinny_kernel: the reduction buffer, or the (larger) activation tile it is aliased with
+static size_t skinny_lds_bytes(int nw, int rb, int steps, bool x_lds) {
+  const size_t red = (size_t)nw * rb * 4096;
+  const size_t tile = x_lds ? (size_t)rb * 32 * ((size_t)nw * steps * 32 + 16) : 0;
+  return std::max(red, tile);
+}
+// more than 64 KiB of dynamic LDS needs the opt-in, once per (instantiation, device); std::call_once: two contexts may first-launch
+// the same instantiation from two host threads
+template <auto Kern>
+static void skinny_allow_big_lds() {
+  static std::once_flag once[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(once[dev & 63], []() { (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+}
 thread_local int g_skinny_nt = 1;  // nontemporal weight loads in the decode GEMMs (option weights_nontemporal = 0 switches them off: A/B experiments; the 1.8 GB of decoder weights a step streams can never stay cached: -1 % per step)
 
 // ONE = the wave's k-steps fit one batch of loads (steps <= U): straight-line code.  (As a loop, the register reuse of
@@ -93,11 +109,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
                                                               float* __restrict__ slab_, int64_t slab_stride_, int rpb_) {
   // U = k-steps in flight per wave (register budget: U * (1 + RB) * 4); the launcher picks the smallest instantiated
   // U >= steps so that no load is issued twice
-  __shared__ __attribute__((aligned(16))) float red[NW][RB][32 * 32];  // [wave][row group][b*32 + n]
+  // dynamic LDS: the reduction buffer red[wave][row group][b*32 + n] (NW * RB * 4 KiB) and - aliased with it, separated by a
+  // barrier - the activation tile of the LDS-staged form (skinny_lds_bytes)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float (*red)[RB][32 * 32] = (float (*)[RB][32 * 32])smem;
   const bf16_t* Wsh = sgpr_pin_ptr(Wsh_);
   const bf16_t* x = sgpr_pin_ptr(x_);
   const int B = sgpr_pin(B_), N = sgpr_pin(N_), K = sgpr_pin(K_), ksplit = sgpr_pin(ksplit_);
-  const int rpb = sgpr_pin(rpb_);      // rows per n-block of the packed matrix (32 or 20: skinny_rows_per_block)
+  const int rpb = sgpr_pin(rpb_ & 255);      // rows per n-block of the packed matrix (32 or 20: skinny_rows_per_block)
+  const int xl = sgpr_pin(rpb_ >> 8);        // 1: activation tile through LDS (launcher: skinny_x_lds)
   const int steps = sgpr_pin(steps_);  // k-steps per wave = K / 16 / (NW * ksplit), divided on the host: an integer division here is
                                        // ~40 dependent instructions in front of the first load
   float* slab = sgpr_pin_ptr(slab_);
@@ -135,7 +155,59 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const bf16_t* __re
   for (int g = 0; g < RB; ++g)
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[g][j] = 0.f;
-  if constexpr (ONE) {
+  // Activation tile through LDS (round 6).  A fragment load straight from the row-major activations touches 32 lines for 32 B
+  // each (row stride = K) - four times the line work of a weight load, every workgroup of the GEMM again for its k-range.  Here
+  // the workgroup requests its tile (RB * 32 rows x NW * steps * 16 k) COALESCED - 2 NW threads cover consecutive 16-byte chunks
+  // of a row, so 8 threads take one whole 128-byte line - BEFORE the weights (vmcnt retires in order: the tile can then be waited
+  // for while the U weight loads fly on), parks it in LDS (rows padded by 16 B: ds_read_b128 of 8 consecutive rows covers all
+  // banks) and reads the MFMA fragments back.  Same fragments, same MFMA order: bit-identical to the register form.  Measured
+  // (NW = 4, one row group, large-v3 decode, 32 rows): 368.9 -> 357.3 ms per 128-token decode.
+  constexpr bool XLC = ONE && (NW == 4 || (NW == 8 && RB == 1));
+  if (XLC && xl) {
+    if constexpr (XLC) {
+    constexpr int TPR = 2 * NW;                       // threads per tile row (each pass of the workgroup covers 32 rows)
+    const int xrow = tid / TPR, xcq = tid % TPR;
+    const int stride = NW * steps * 32 + 16;          // bytes per LDS row
+    u32x4 w[U], xr[RB][U], xv[RB][U];
+#pragma unroll
+    for (int g = 0; g < RB; ++g) {
+      const bf16_t* xg = x + (int64_t)min(g * 32 + xrow, B - 1) * K + (int64_t)(ks * NW * steps) * 16 + xcq * 8;
+#pragma unroll
+      for (int u = 0; u < U; ++u) xr[g][u] = *(const u32x4*)(xg + min(u, steps - 1) * TPR * 8);
+    }
+    prefetch_epilogue();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = min(u, steps - 1);
+      if constexpr (NT) w[u] = __builtin_nontemporal_load(wp + (int64_t)i * wstep); else w[u] = wp[(int64_t)i * wstep];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(U) : "memory");   // tile pieces (and epilogue operands) landed; the U weight loads fly on
+#pragma unroll
+    for (int g = 0; g < RB; ++g)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (u < steps) *(u32x4*)(smem + (g * 32 + xrow) * stride + (u * TPR + xcq) * 16) = xr[g][u];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int g = 0; g < RB; ++g)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        xv[g][u] = *(const u32x4*)(smem + (g * 32 + (lane & 31)) * stride + ((wave * steps + min(u, steps - 1)) * 2 + (lane >> 5)) * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // every fragment is in registers: the tile's LDS becomes the reduction buffer
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < steps) {
+#pragma unroll
+        for (int g = 0; g < RB; ++g)
+          acc[g] = N16<T16>::mfma32(*(s16x8*)&w[u], *(s16x8*)&xv[g][u], acc[g]);
+      }
+    }
+  } else if constexpr (ONE) {
     u32x4 w[U], xv[RB][U];
     // Issue order (round 6): ALL weight fragments first - they come from HBM and are the long pole -, then the activation
     // fragments row group by row group.  A lane's activation pieces of consecutive k-steps are 32 B apart in ONE 128-byte line
@@ -434,8 +506,16 @@ bool launch_gemm_skinny(const T16* Wsh_, const T16* x_, int B, int N, int K, con
   dim3 grid(n_blocks, ksplit);
 #define TTASR_SKINNY(NW_, RB_, U_, ONE_)                                                                                              \
   do {                                                                                                                                \
-    if (g_skinny_nt) hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpb); \
-    else hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), 0, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpb); \
+    const bool xl_ = g_skinny_x_lds && ONE_ && (NW_ == 4 || (NW_ == 8 && RB_ == 1));                                                  \
+    const size_t lds_ = skinny_lds_bytes(NW_, RB_, steps, xl_);                                                                       \
+    const int rpbx_ = rpb | (xl_ ? 256 : 0);                                                                                          \
+    if (g_skinny_nt) {                                                                                                                \
+      if (lds_ > 65536) skinny_allow_big_lds<gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>>();                                     \
+      hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, true, ONE_>), grid, dim3(NW_ * 64), lds_, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpbx_); \
+    } else {                                                                                                                          \
+      if (lds_ > 65536) skinny_allow_big_lds<gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>>();                                    \
+      hipLaunchKernelGGL((gemm_skinny_kernel<T16, NW_, RB_, U_, false, ONE_>), grid, dim3(NW_ * 64), lds_, s, Wsh, x, B, N, K, ksplit, steps, e, slab, slab_stride, rpbx_); \
+    }                                                                                                                                 \
   } while (0)
 #define TTASR_SKINNY_U(NW_, RB_, UMAX_)                                            \
   do {                                                                             \

@@ -470,11 +470,14 @@ def test_round4_options_are_bit_identical_to_their_off_form():
         # 180 tail tiles, fc1 1 780 + 140)
         # and `enc_ln_defer` - one f32 read-modify-write of the encoder's residual stream per layer instead of two (the LayerNorm
         # after the attention out-projection only peeks at x + delta; the next one folds both deltas in)
+        # and (round 6) `dec_x_lds` - the decode GEMMs' activation tile staged through LDS with coalesced loads instead of
+        # fragment loads straight from the row-major activations
         for key_vals in ({}, {"xattn_pipeline": 0}, {"enc_gemm_persistent": 0}, {"xkv_grouped": 0}, {"enc_gemm_tail": 0}, {"enc_ln_defer": 0},
+                         {"dec_x_lds": 0},
                          {"xattn_pipeline": 0, "enc_gemm_persistent": 0, "multi_step_graph": 0, "xkv_grouped": 0, "enc_gemm_tail": 0,
-                          "enc_ln_defer": 0}):
+                          "enc_ln_defer": 0, "dec_x_lds": 0}):
             for k, v in {"xattn_pipeline": 1, "enc_gemm_persistent": 1, "multi_step_graph": 1, "xkv_grouped": 1, "enc_gemm_tail": 1,
-                         "enc_ln_defer": 1, **key_vals}.items():
+                         "enc_ln_defer": 1, "dec_x_lds": 1, **key_vals}.items():
                 e.set_option(k, v)
             e.log_mel(cl, want_output=False)
             enc = e.encode(16, want_output=True)

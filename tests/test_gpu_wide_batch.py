@@ -122,3 +122,40 @@ def test_measured_width_at_120_rows():
         if agree[a]:
             assert abs(float(wide.sum_logprob[a]) - float(narrow.sum_logprob[a % 6])) < 0.05 * max(1, len(wide.tokens[a])), a
     e.close()
+
+
+@pytest.mark.parametrize("preset", ["tiny", "large-v3-w2"])
+def test_lds_staged_activations_are_bit_identical_at_every_width(preset):
+    """`dec_x_lds` (round 6): the decode GEMMs request their activation tile coalesced, park it in LDS and read the MFMA fragments
+    back - the same fragments in the same MFMA order as the fragment loads straight from memory.  Held bit for bit on the step
+    logits and on greedy / beam results for 1 ... 4 row groups (also a ragged last group), at two geometries (K = 384 / 1536 and
+    1280 / 5120: different k-steps per wave, K splits, waves per workgroup)."""
+    from taiwan_tongues_asr_ce_amd.engine import Engine
+    pd = PRESETS[preset]
+    e = Engine(pd, COMPUTE_BF16, 128)
+    e.load_weights(synth.iter_weights(pd))
+    st = e.special
+    base = [synth.noise_clip(0), synth.tonal_clip(1), synth.burst_clip(2), synth.noise_clip(3), synth.tonal_clip(4)]
+    prompt = [st.sot, st.lang_zh, st.transcribe, st.no_timestamps]
+    for B in (1, 5, 32, 40, 70, 97, 128):
+        e.log_mel([base[b % 5] for b in range(B)], want_output=False)
+        e.encode(B)
+        outs = []
+        for on in (1, 0):
+            e.set_option("dec_x_lds", on)
+            e.decode_reset(B)
+            lg = [e.decode_step([t] * B).copy() for t in prompt + [1234]]
+            r = e.generate([prompt] * B, e.gen_opts(6, False, suppress_eot=True))
+            outs.append((lg, r.tokens, r.sum_logprob.copy()))
+        assert all(np.array_equal(a, b) for a, b in zip(outs[0][0], outs[1][0])), (preset, B)
+        assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][2], outs[1][2]), (preset, B)
+    e.log_mel(base * 4, want_output=False)
+    e.encode(20)
+    beams = []
+    for on in (1, 0):
+        e.set_option("dec_x_lds", on)
+        r = e.generate_beam([prompt] * 20, 5, e.gen_opts(8, False))
+        beams.append((r.tokens, r.sum_logprob.copy()))
+    assert beams[0][0] == beams[1][0] and np.array_equal(beams[0][1], beams[1][1]), preset
+    e.set_option("dec_x_lds", 1)
+    e.close()
