@@ -214,14 +214,13 @@ void run_decode_rows(ttasr_ctx* c, int row0, int n, int mode, int total_rows) {
   auto slices = [&](int kind, int N, int K) {
     if (!skinny) return 1;
     int want = c->ks_want[kind];
-    // qkv (N = 3 d: already 3x the workgroups of the other GEMMs): 2 slices measured best (5.35 vs 6.02 us at large-v3) - with ONE
-    // 32-row group; wider batches (beam search, streaming: 33-128 rows) keep the automatic choice, whose k-steps per wave fit the
-    // straight-line form (2 slices there meant the looped form: 10.4 us at 40 rows)
-    if (kind == 2 && want == 0 && n <= 32 && (N + 31) / 32 >= 96) want = 2;
-    // out-proj at d = 1280 with one 32-row group: 5 slices (200 workgroups x 4 k-steps per wave) instead of the automatic 4 (160 x 5)
-    // measured 2.8438 vs 2.8494 ms per decode step in two interleaved rounds (round 5; `tools/decode_variants.py
-    // --variants auto,d5`): kept.  The q GEMM stays at 4: the attention consumers sum at most 4 slabs.
-    if (kind == 0 && want == 0 && n <= 32 && K == 1280 && N == 1280 && skinny_rows_per_block(N, K) == 32) want = 5;
+    // Round 6: with the activation tile staged through LDS (kernels_skinny.hip) the K-split optimum of two GEMMs moved - re-swept
+    // with `tools/decode_variants.py` (large-v3, 32 rows, decode of 128 tokens, two interleaved rounds): qkv UNSPLIT (120 n-blocks x
+    // 8 waves, the self-attention reads q, k, v directly) 354.7-355.5 ms against 356.9-357.7 with the 2 slices that rounds 3-5
+    // used; out-proj at the automatic 4 slices 355.4-356.1 against the 5 of round 5; both 352.7-352.9.  Wider batches (beam
+    // search, streaming: 33-128 rows) keep the automatic choice, whose k-steps per wave fit the straight-line form.
+    // (A different K split is a different summation order: the 16-bit token CRC of the benchmark was re-recorded with this change.)
+    if (kind == 2 && want == 0 && n <= 32 && (N + 31) / 32 >= 96) want = 1;
     int ks = gemm_skinny_ksplit(n, N, K, want);
     if ((kind == 1 || kind == 2) && ks > 4) ks = gemm_skinny_ksplit(n, N, K, 4);
     return ks;

@@ -27,11 +27,18 @@ VARIANTS = {
     "f16": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 16},
     "f10": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 2, "ksplit_fc2": 10},
     "qkv4": {"ksplit_out": 4, "ksplit_q": 4, "ksplit_qkv": 4, "ksplit_fc2": 8},
+    # round 6 (the activation tile now comes through LDS: the K-split optimum may have moved)
+    "d4": {"ksplit_out": 4}, "d8": {"ksplit_out": 8}, "d10": {"ksplit_out": 10}, "d2": {"ksplit_out": 2},
+    "f4": {"ksplit_fc2": 4}, "f5": {"ksplit_fc2": 5}, "f16only": {"ksplit_fc2": 16},
+    "qkv1": {"ksplit_qkv": 1}, "qkv4only": {"ksplit_qkv": 4}, "q2": {"ksplit_q": 2}, "q1": {"ksplit_q": 1},
+    "d4qkv1": {"ksplit_out": 4, "ksplit_qkv": 1}, "d4qkv1q2": {"ksplit_out": 4, "ksplit_qkv": 1, "ksplit_q": 2},
+    "d4qkv1f16": {"ksplit_out": 4, "ksplit_qkv": 1, "ksplit_fc2": 16}, "d2qkv1": {"ksplit_out": 2, "ksplit_qkv": 1},
+    "x_regs": {"dec_x_lds": 0},
     "vocab_generic": {"vocab_persistent": 0},             # round-2 vocabulary GEMM: one workgroup per 32 outputs
     "w_plain": {"weights_nontemporal": 0},
     "xattn_plain": {"xattn_nontemporal": 0},
 }
-DEFAULTS = {"vocab_persistent": 1, "prefill_ns_min": 2, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
+DEFAULTS = {"dec_x_lds": 1, "vocab_persistent": 1, "prefill_ns_min": 2, "ksplit_out": 0, "ksplit_q": 0, "ksplit_qkv": 0, "ksplit_fc2": 0, "weights_nontemporal": 1,
             "xattn_nontemporal": 1}
 
 
